@@ -1,0 +1,485 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the reference's own Python code on CPU.
+
+Run in the build container only (needs /root/reference, which never travels to
+the GPU box):   python tools/make_golden.py
+
+How the reference is imported (no reference source is modified or copied):
+  * sys.path gets /root/reference/object_detection/yolov5 and /root/reference/object_detection;
+  * third-party packages that are absent here (cv2, seaborn, thop, torchvision) are
+    replaced by stub modules; the stub ``torchvision.ops.nms`` is the oracle's C
+    greedy NMS (oracle/csrc/oracle_nms.c), and every call to it is recorded so the
+    fixture pins everything the reference does *around* that third-party kernel;
+  * the reference targets torch 1.10, where ``LongTensor.clamp_(0, float0dTensor)``
+    casts the bound to the tensor's dtype; torch 2.10 raises instead, so
+    ``Tensor.clamp_`` is wrapped to restore that cast (utils/loss.py:217).
+  * modules that reach the network at import time (utils/plots.py, models/*) are
+    never imported.
+All random inputs come from numpy's legacy ``RandomState`` (bit-stable stream).
+"""
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+OUT = os.path.join(REPO, "tests", "golden")
+REF = "/root/reference/object_detection"
+
+from oracle import nms as oracle_nms  # noqa: E402  (stand-in for the absent torchvision kernel)
+
+NMS_CALLS = []
+
+
+def _recording_nms(boxes, scores, thr):
+    keep = oracle_nms.nms(boxes, scores, thr)
+    NMS_CALLS.append((boxes.detach().clone().numpy(), scores.detach().clone().numpy(), float(thr), keep.numpy()))
+    return keep
+
+
+def install_stubs():
+    for name in ("cv2", "seaborn", "thop"):
+        sys.modules[name] = MagicMock()
+    tv = types.ModuleType("torchvision")
+    tv.__version__ = "0.11.1"
+    tv.ops = types.ModuleType("torchvision.ops")
+    tv.ops.nms = _recording_nms
+    tv.ops.sigmoid_focal_loss = None
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.ops"] = tv.ops
+
+    orig = torch.Tensor.clamp_
+
+    def clamp_(self, min=None, max=None):
+        def cast(v):
+            if isinstance(v, torch.Tensor) and v.dim() == 0:
+                v = v.item()
+            if v is not None and not self.is_floating_point():
+                v = int(v)
+            return v
+        return orig(self, cast(min), cast(max))
+    torch.Tensor.clamp_ = clamp_
+
+
+def load_reference():
+    install_stubs()
+    sys.path.insert(0, os.path.join(REF, "yolov5"))
+    sys.path.insert(0, REF)
+    import utils.metrics as y_metrics
+    import utils.general as y_general
+    import utils.loss as y_loss
+    import loss as a_loss
+    import detectors.centernet.loss as c_loss
+    import detectors.centernet.dataset as c_data
+    return y_metrics, y_general, y_loss, a_loss, c_loss, c_data
+
+
+from tests._synth import (f32, rand_boxes_xywh, synth_targets, synth_head, synth_pred, dedupe_scores,  # noqa: E402
+                          make_big_pred)
+
+
+def T(a):
+    return torch.from_numpy(f32(a))
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}.npz: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+# ----------------------------------------------------------------------------- inputs
+def special_pairs():
+    """xywh pairs: identical, disjoint, nested, touching edges, zero w/h, tiny boxes, equal corners."""
+    a = [[.5, .5, .2, .3], [.2, .2, .1, .1], [.5, .5, .4, .4], [.3, .5, .2, .2], [.5, .5, 0., .2],
+         [.5, .5, .2, 0.], [.5, .5, 0., 0.], [.5, .5, 1e-4, 1e-4], [.5, .5, 1e-7, 2e-7], [.25, .25, .5, .5],
+         [0., 0., 0., 0.], [.5, .5, .2, .2]]
+    b = [[.5, .5, .2, .3], [.8, .8, .1, .1], [.5, .5, .1, .1], [.5, .5, .2, .2], [.5, .5, .2, .2],
+         [.5, .5, .2, .2], [.5, .5, 0., 0.], [.50005, .5, 1e-4, 1e-4], [.5, .5, 2e-7, 1e-7], [.5, .25, .5, .5],
+         [0., 0., 0., 0.], [.6, .5, .2, .4]]
+    return f32(a), f32(b)
+
+
+def xywh_to_xyxy_np(b):
+    return f32(np.stack([b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2, b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2], 1))
+
+
+MODE_FLAGS = {"iou": {}, "giou": {"GIoU": True}, "diou": {"DIoU": True}, "ciou": {"CIoU": True}}
+
+
+# ----------------------------------------------------------------------------- generators
+def gen_bbox_iou(y_metrics, a_loss):
+    rs = np.random.RandomState(11)
+    out = {}
+    sa, sb = special_pairs()
+    for tag, n in (("n1", 1), ("n257", 257), ("n2048", 2048), ("special", len(sa))):
+        if tag == "special":
+            p, t = sa, sb
+        else:
+            p, t = rand_boxes_xywh(rs, n), rand_boxes_xywh(rs, n)
+            t[: n // 4] = p[: n // 4] + f32(rs.normal(0, 0.02, (n // 4, 4)))     # near-matches
+            t[:, 2:] = np.abs(t[:, 2:])
+        for fmt in ("xywh", "xyxy"):
+            pp, tt = (p, t) if fmt == "xywh" else (xywh_to_xyxy_np(p), xywh_to_xyxy_np(t))
+            out[f"{tag}_{fmt}_box1"] = pp
+            out[f"{tag}_{fmt}_box2"] = tt
+            for mode, flags in MODE_FLAGS.items():
+                b1 = T(pp).T.contiguous().requires_grad_(True)                # (4,n) as loss.py:135 passes it
+                val = y_metrics.bbox_iou(b1, T(tt), x1y1x2y2=(fmt == "xyxy"), **flags)
+                g, = torch.autograd.grad(val.sum(), b1)
+                out[f"{tag}_{fmt}_{mode}_out"] = val.detach().numpy()
+                out[f"{tag}_{fmt}_{mode}_grad"] = g.numpy()                    # (4,n)
+    # author's [...,4] layout on a 3-d batch, default xywh
+    p, t = rand_boxes_xywh(rs, 60).reshape(3, 20, 4), rand_boxes_xywh(rs, 60).reshape(3, 20, 4)
+    out["lastdim_box1"], out["lastdim_box2"] = p, t
+    for mode, flags in MODE_FLAGS.items():
+        b1 = T(p).requires_grad_(True)
+        val = a_loss.bbox_iou(b1, T(t), **flags)
+        g, = torch.autograd.grad(val.sum(), b1)
+        out[f"lastdim_{mode}_out"], out[f"lastdim_{mode}_grad"] = val.detach().numpy(), g.numpy()
+    b1 = T(xywh_to_xyxy_np(p.reshape(-1, 4)).reshape(3, 20, 4))
+    out["lastdim_xyxy_ciou_out"] = a_loss.bbox_iou(b1, T(xywh_to_xyxy_np(t.reshape(-1, 4)).reshape(3, 20, 4)),
+                                                   x1y1x2y2=True, CIoU=True).numpy()
+    # sanity vector quoted in the survey
+    v = y_metrics.bbox_iou(T([[.5, .5, .2, .3]]).T, T([[.52, .48, .25, .28]]), x1y1x2y2=False, CIoU=True)
+    out["sanity_ciou"] = v.numpy()
+    save("bbox_iou", **out)
+
+
+def centernet_maps(rs, b, c, w, h, n_obj):
+    """Synthetic head outputs + label maps; label maps come from the reference's own target code later."""
+    pred_cls = f32(rs.normal(-2.0, 1.5, (b, c, w, h)))
+    pred_size = f32(np.abs(rs.normal(6, 3, (b, 2, w, h))))
+    pred_off = f32(rs.uniform(0, 1, (b, 2, w, h)))
+    return pred_cls, pred_size, pred_off
+
+
+def gen_centernet(a_loss, c_loss, c_data):
+    import dataset as ds_mod
+    rs = np.random.RandomState(23)
+    out = {}
+    B, C, W, H = 2, 3, 40, 36            # W != H so that an x/y swap cannot hide
+    inp = (W * 4, H * 4)
+
+    # ---- target drawing through the reference's own __getitem__ (dataset.py:96-161)
+    label_sets = [
+        f32([[10, 20, 50, 90, 0], [12, 22, 52, 88, 1], [100, 30, 140, 60, 2], [0, 0, 8, 8, 1],
+             [150, 130, 170, 150, 0], [30, 30, 30, 60, 2], [-20, 40, 25, 70, 1], [90, 100, 91, 101, 0]]),
+        f32([[60, 60, 100, 100, 2], [61, 61, 99, 99, 0], [5, 100, 45, 140, 1]]),
+        np.zeros((0, 5), dtype=np.float32),
+    ]
+    feed = {}
+    ds_mod.YOLODataset.__getitem__ = lambda self, idx: (None, None, len(feed["l"]), feed["l"])
+    ds = object.__new__(c_data.CenternetDataset)
+    ds.length, ds.input_shape, ds.output_shape, ds.num_classes = 1, inp, (W, H), C
+    drawn = []
+    for k, lab in enumerate(label_sets):
+        feed["l"] = lab
+        item = ds[0]
+        drawn.append(item[4:])
+        out[f"targets{k}_labels"] = lab
+        for nm, arr in zip(("cls", "size", "offset", "mask"), item[4:]):
+            out[f"targets{k}_{nm}"] = f32(arr)
+    out["targets_input_shape"] = np.array(inp)
+    out["targets_output_shape"] = np.array((W, H))
+
+    # ---- box loss through compute_losses (centernet/loss.py:16-28) + IoULossWithMask (loss.py:102-115)
+    pred_cls, pred_size, pred_off = centernet_maps(rs, B, C, W, H, 0)
+    lab_cls = f32(np.stack([drawn[0][0], drawn[1][0]]))
+    lab_size = f32(np.stack([drawn[0][1], drawn[1][1]]))
+    lab_off = f32(np.stack([drawn[0][2], drawn[1][2]]))
+    lab_mask = f32(np.stack([drawn[0][3], drawn[1][3]]))
+    # make the predictions near the labels on positive cells so CIoU is in its interesting range
+    pos = lab_mask[:, None] > 0
+    pred_size = np.where(pos, lab_size * f32(rs.uniform(0.6, 1.5, lab_size.shape)), pred_size).astype(np.float32)
+    pred_off = np.where(pos, lab_off + f32(rs.normal(0, 0.3, lab_off.shape)), pred_off).astype(np.float32)
+    crit = {"cls": lambda a, b: torch.zeros(()), "box": a_loss.IoULossWithMask(CIoU=True), "size": None, "offset": None}
+    for tag, mask in (("pos", lab_mask), ("zero", np.zeros_like(lab_mask)), ("dense", f32(rs.uniform(0, 1, lab_mask.shape) < 0.3))):
+        ps, po = T(pred_size).requires_grad_(True), T(pred_off).requires_grad_(True)
+        losses = {}
+        c_loss.compute_losses([T(pred_cls), ps, po], [T(lab_cls), T(lab_size), T(lab_off), T(mask)], crit, losses)
+        gs, go = torch.autograd.grad(losses["box"], [ps, po], allow_unused=True)
+        out[f"loss_{tag}_mask"] = mask
+        out[f"loss_{tag}_value"] = losses["box"].detach().numpy()
+        out[f"loss_{tag}_grad_size"] = gs.numpy()
+        out[f"loss_{tag}_grad_offset"] = go.numpy()
+    out.update(loss_pred_cls=pred_cls, loss_pred_size=pred_size, loss_pred_offset=pred_off,
+               loss_lab_cls=lab_cls, loss_lab_size=lab_size, loss_lab_offset=lab_off)
+    out["offset_to_coord"] = c_loss.offset_to_coord(T(pred_off)).numpy()
+    # IoULossWithMask called directly on (B,4,W,H) maps; flags other than CIoU are ignored by the reference
+    p4 = T(np.concatenate([pred_off * 5, pred_size], 1)).requires_grad_(True)
+    t4 = T(np.concatenate([lab_off * 5, lab_size + 1], 1))
+    val = a_loss.IoULossWithMask(GIoU=True)(p4, t4, T(lab_mask))
+    g, = torch.autograd.grad(val, p4)
+    out.update(direct_pred=p4.detach().numpy(), direct_target=t4.numpy(), direct_mask=lab_mask,
+               direct_value=val.detach().numpy(), direct_grad=g.numpy())
+
+    # ---- decode / post-process (dataset.py:164-297)
+    heat = f32(rs.normal(-1.0, 1.2, (B + 1, C, W, H)))
+    heat[0, 1, 5, 7] = 3.0; heat[0, 1, 5, 8] = 3.0          # equal neighbours: both survive the 3x3 peak test
+    heat[0, 2, 20, 30] = 4.0; heat[0, 0, 21, 30] = 3.5      # different classes, adjacent cells
+    heat[0, 0, 0, 0] = 2.5; heat[0, 2, W - 1, H - 1] = 2.8  # corners
+    heat[1, 0, 10, 10] = 2.0; heat[1, 1, 10, 10] = 2.0      # class tie in one cell -> first class
+    heat[2] = -3.0                                          # nothing above threshold
+    size = f32(np.abs(rs.normal(6, 3, (B + 1, 2, W, H))))
+    off = f32(rs.uniform(0, 1, (B + 1, 2, W, H)))
+    out.update(dec_heat=heat, dec_size=size, dec_offset=off)
+    out["pool_nms"] = c_data.pool_nms(T(heat)).numpy()
+    for conf in (0.9, 0.3):
+        dets = c_data.decode_bbox(T(heat), T(size), T(off), conf, "cpu")
+        for k, d in enumerate(dets):
+            out[f"decode_c{conf}_img{k}"] = d.numpy() if len(d) else np.zeros((0, 6), np.float32)
+        for need in (False, True):
+            NMS_CALLS.clear()
+            post = c_data.postprocess([d.clone() if len(d) else d for d in dets], need, 640, 160.0, False, 0.4)
+            for k, d in enumerate(post):
+                out[f"post_c{conf}_nms{int(need)}_img{k}"] = np.zeros((0, 6), np.float32) if d is None else d
+        post = c_data.postprocess([d.clone() if len(d) else d for d in dets], True, 500, 640.0, True, 0.4)
+        for k, d in enumerate(post):
+            out[f"post_c{conf}_letterbox_img{k}"] = np.zeros((0, 6), np.float32) if d is None else d
+    post = c_data.postprocess_predictions([T(heat), T(size), T(off)], 640, "cpu")
+    for k, d in enumerate(post):
+        out[f"postpred_img{k}"] = np.zeros((0, 6), np.float32) if d is None else d
+    save("centernet", **out)
+
+
+def gen_pairwise(y_metrics):
+    rs = np.random.RandomState(31)
+    out = {}
+    for tag, (n, m) in (("0x5", (0, 5)), ("7x5", (7, 5)), ("100x300", (100, 300)), ("65x129", (65, 129))):
+        a, b = xywh_to_xyxy_np(rand_boxes_xywh(rs, n, 640)).reshape(n, 4), xywh_to_xyxy_np(rand_boxes_xywh(rs, m, 640))
+        if n and m:
+            b[0] = a[0]
+        out[f"box_iou_{tag}_a"], out[f"box_iou_{tag}_b"] = a, b
+        out[f"box_iou_{tag}_out"] = y_metrics.box_iou(T(a).reshape(n, 4), T(b)).numpy()
+        wa, wb = f32(rs.uniform(1, 300, (n, 2))), f32(rs.uniform(1, 300, (m, 2)))
+        out[f"wh_iou_{tag}_a"], out[f"wh_iou_{tag}_b"] = wa, wb
+        out[f"wh_iou_{tag}_out"] = y_metrics.wh_iou(T(wa).reshape(n, 2), T(wb)).numpy()
+    box1 = f32([100, 120, 300, 280])
+    box2 = xywh_to_xyxy_np(rand_boxes_xywh(rs, 50, 640))
+    out.update(ioa_box1=box1, ioa_box2=box2, ioa_out=y_metrics.bbox_ioa(box1, box2))
+    save("pairwise", **out)
+
+
+def edge_targets(nx_list=(80, 40, 20)):
+    """Targets sitting exactly on decision boundaries of loss.py:191-217."""
+    rows = []
+    for nx in nx_list:
+        for gx, gy in ((2.5, 3.5), (1.0, 1.0), (0.25, 0.75), (1.5, nx - 1.5), (nx - 1.0, nx - 0.5),
+                       (nx - 0.25, 0.0), (float(nx), float(nx)), (3.0, 4.0), (3.4999998, 3.5000002)):
+            rows.append([0, 1, gx / nx, gy / nx, 0.1, 0.1])
+    for s, (aw, ah) in zip((8, 16, 32), ((10, 13), (30, 61), (116, 90))):       # wh ratio exactly 4, 1/4, just inside
+        for k in (4.0, 0.25, 3.9999, 0.2500001, 4.0001):
+            rows.append([1, 2, 0.5, 0.5, aw * k / 640, ah / 640])
+    return f32(rows)
+
+
+def fake_model(y_loss, nc, hyp, anchors, strides):
+    class Det:
+        pass
+    det = Det()
+    det.na, det.nc, det.nl, det.anchors, det.stride = anchors.shape[1], nc, anchors.shape[0], anchors, strides
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+            self.model = [det]
+    m = M()
+    m.hyp = hyp
+    return m
+
+
+HYP = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+
+
+def yolo_anchors():
+    a = torch.tensor([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]]).float()
+    strides = torch.tensor([8., 16., 32.])
+    return a.view(3, 3, 2) / strides.view(-1, 1, 1), strides
+
+
+def gen_build_targets(y_loss):
+    rs = np.random.RandomState(41)
+    anchors, strides = yolo_anchors()
+    cl = y_loss.ComputeLoss(fake_model(y_loss, 80, dict(HYP), anchors, strides))
+    out = {"anchors": anchors.numpy()}
+    shapes = [(8, 3, 80, 80, 85), (8, 3, 40, 40, 85), (8, 3, 20, 20, 85)]
+    p = [torch.empty(s) for s in shapes]
+    cases = {"nt0": np.zeros((0, 6), np.float32), "nt1": synth_targets(rs, 1, 8), "nt80": synth_targets(rs, 80, 8),
+             "nt640": synth_targets(rs, 640, 8), "edges": edge_targets()}
+    # non-square grid: catches any nx/ny swap
+    p_rect = [torch.empty(4, 3, 48, 80, 85), torch.empty(4, 3, 24, 40, 85), torch.empty(4, 3, 12, 20, 85)]
+    cases["rect"] = synth_targets(rs, 120, 4)
+    for tag, tg in cases.items():
+        pp = p_rect if tag == "rect" else p
+        tcls, tbox, indices, anch = cl.build_targets(pp, T(tg).reshape(-1, 6))
+        out[f"{tag}_targets"] = tg
+        out[f"{tag}_shapes"] = np.array([[x.shape[2], x.shape[3]] for x in pp])
+        for l in range(3):
+            b, a, gj, gi = indices[l]
+            out[f"{tag}_l{l}_idx"] = torch.stack((b, a, gj, gi), 1).numpy().astype(np.int64)
+            out[f"{tag}_l{l}_tbox"] = tbox[l].numpy()
+            out[f"{tag}_l{l}_anch"] = anch[l].numpy()
+            out[f"{tag}_l{l}_tcls"] = tcls[l].numpy().astype(np.int64)
+    save("build_targets", **out)
+
+
+def gen_compute_loss(y_loss):
+    rs = np.random.RandomState(53)
+    anchors, strides = yolo_anchors()
+    out = {"anchors": anchors.numpy()}
+
+    def run(tag, img, bs, nc, targets, hyp_over=None, autobalance=False, calls=1, store_grads=True):
+        hyp = dict(HYP)
+        hyp.update(hyp_over or {})
+        cl = y_loss.ComputeLoss(fake_model(y_loss, nc, hyp, anchors, strides), autobalance=autobalance)
+        levels = synth_head(rs, bs, img, nc)
+        out[f"{tag}_targets"] = targets
+        out[f"{tag}_meta"] = np.array([img, bs, nc, int(autobalance), calls])
+        out[f"{tag}_hyp"] = np.array([hyp[k] for k in ("box", "cls", "cls_pw", "obj", "obj_pw", "anchor_t", "fl_gamma", "label_smoothing")])
+        for c in range(calls):
+            p = [T(x).requires_grad_(True) for x in levels]
+            loss, items = cl(p, T(targets).reshape(-1, 6))
+            grads = torch.autograd.grad(loss, p, allow_unused=True)
+            out[f"{tag}_call{c}_loss"] = loss.detach().numpy()
+            out[f"{tag}_call{c}_items"] = items.numpy()
+            if store_grads:
+                for l in range(3):
+                    out[f"{tag}_call{c}_grad{l}"] = grads[l].numpy()
+        for l in range(3):
+            out[f"{tag}_p{l}"] = levels[l]
+        if autobalance:
+            out[f"{tag}_balance"] = np.array(cl.balance)
+
+    t128 = synth_targets(rs, 24, 2, 80)
+    t128[5] = t128[4]                       # exact duplicate target -> duplicate (b,a,gj,gi): last writer wins
+    t128[6, :] = t128[4, :]; t128[6, 1] = 7  # same cell, different class
+    t128[7, 2:4] = t128[4, 2:4]; t128[7, 4:6] = t128[4, 4:6] * 1.1
+    run("base128", 128, 2, 80, t128)
+    t64 = synth_targets(rs, 10, 2, 12)
+    t64[3] = t64[2]
+    run("nt0", 64, 2, 12, np.zeros((0, 6), np.float32))
+    run("smooth", 64, 2, 12, t64, {"label_smoothing": 0.1})
+    run("focal", 64, 2, 12, t64, {"fl_gamma": 1.5})
+    run("posw", 64, 2, 12, t64, {"cls_pw": 0.7, "obj_pw": 1.3, "box": 0.07, "cls": 0.3, "obj": 0.8})
+    run("autobal", 64, 2, 12, t64, None, autobalance=True, calls=2)
+    run("nc1", 64, 2, 1, np.concatenate([t64[:, :1], np.zeros((10, 1), np.float32), t64[:, 2:]], 1))
+    save("compute_loss", **out)
+
+
+def pack_list(out, key, dets):
+    out[key + "_counts"] = np.array([d.shape[0] for d in dets])
+    out[key + "_dets"] = np.concatenate([d.numpy() for d in dets], 0) if dets else np.zeros((0, 6), np.float32)
+
+
+def gen_nms(y_general):
+    rs = np.random.RandomState(67)
+    out = {}
+    nc = 16
+    pred = dedupe_scores(synth_pred(rs, 3, 1008, nc), 0.001)
+    pred[2, :, 4] = 0.0                                                   # image with no candidates at all
+    pred[1, 5, 4] = 0.25                                                  # objectness exactly at threshold -> rejected (strict >)
+    out["pred"] = pred
+    labels = [T([[3, 100, 100, 50, 60], [5, 300, 310, 80, 40]]), torch.zeros((0, 5)), T([[1, 200, 200, 90, 90]])]
+    out["labels0"], out["labels2"] = labels[0].numpy(), labels[2].numpy()
+    variants = {
+        "default": {},
+        "multi": dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+        "multi_c25": dict(conf_thres=0.25, iou_thres=0.45, multi_label=True),
+        "agnostic": dict(agnostic=True),
+        "agnostic_multi": dict(conf_thres=0.05, agnostic=True, multi_label=True),
+        "classes": dict(conf_thres=0.05, classes=[0, 2, 7]),
+        "classes_multi": dict(conf_thres=0.05, classes=[0, 2, 7], multi_label=True),
+        "maxdet1": dict(max_det=1),
+        "maxdet5_multi": dict(conf_thres=0.01, multi_label=True, max_det=5),
+        "labels": dict(conf_thres=0.1, labels=labels),
+        "iou0": dict(iou_thres=0.0),
+        "iou1": dict(iou_thres=1.0),
+        "conf0": dict(conf_thres=0.0, max_det=1000),
+        "conf1": dict(conf_thres=1.0),
+    }
+    for tag, kw in variants.items():
+        NMS_CALLS.clear()
+        dets = y_general.non_max_suppression(T(pred).clone(), **kw)
+        pack_list(out, tag, dets)
+        out[tag + "_nms_sizes"] = np.array([c[0].shape[0] for c in NMS_CALLS])
+        if tag in ("default", "multi"):                                   # pin what reaches the third-party kernel
+            out[tag + "_nms_boxes"] = np.concatenate([c[0] for c in NMS_CALLS], 0)
+            out[tag + "_nms_scores"] = np.concatenate([c[1] for c in NMS_CALLS], 0)
+            out[tag + "_nms_keep"] = np.concatenate([c[3] for c in NMS_CALLS], 0)
+
+    # single class (nc=1): multi_label is forced off (general.py:667)
+    p1 = dedupe_scores(synth_pred(rs, 2, 600, 1), 0.001)
+    out["nc1_pred"] = p1
+    pack_list(out, "nc1", y_general.non_max_suppression(T(p1).clone(), conf_thres=0.1, multi_label=True))
+
+    # more than max_nms candidates (general.py:716-717); inputs are regenerated from the seed by the tests
+    big = make_big_pred()
+    NMS_CALLS.clear()
+    dets = y_general.non_max_suppression(T(big).clone(), conf_thres=0.01, iou_thres=0.5, multi_label=True, max_det=300)
+    assert NMS_CALLS[0][0].shape[0] == 30000, NMS_CALLS[0][0].shape
+    out["big_pred_checksum"] = np.array([big.sum(dtype=np.float64)])
+    pack_list(out, "big", dets)
+
+    # score ties: the reference's unstable sorts forced to stable=True (the order this build pins)
+    tie = synth_pred(rs, 2, 400, 4, n_obj=5, k_per_obj=20)
+    tie[..., 4] = np.round(tie[..., 4] * 8) / 8
+    tie[..., 5:] = np.round(tie[..., 5:] * 4) / 4
+    out["tie_pred"] = tie
+    orig_argsort, orig_sort = torch.Tensor.argsort, torch.Tensor.sort
+    torch.Tensor.argsort = lambda self, *a, **k: orig_argsort(self, *a, **{**k, "stable": True})
+    try:
+        pack_list(out, "tie", y_general.non_max_suppression(T(tie).clone(), conf_thres=0.05, iou_thres=0.5))
+        pack_list(out, "tie_multi", y_general.non_max_suppression(T(tie).clone(), conf_thres=0.05, iou_thres=0.5, multi_label=True))
+    finally:
+        torch.Tensor.argsort, torch.Tensor.sort = orig_argsort, orig_sort
+    save("nms", **out)
+
+
+def gen_box_utils(y_general):
+    rs = np.random.RandomState(79)
+    out = {}
+    xywh = rand_boxes_xywh(rs, 33, 640)
+    out["xywh"] = xywh
+    out["xywh2xyxy"] = y_general.xywh2xyxy(T(xywh)).numpy()
+    out["xyxy2xywh"] = y_general.xyxy2xywh(T(out["xywh2xyxy"])).numpy()
+    out["xywh2xyxy_np"] = y_general.xywh2xyxy(xywh.copy())
+    xyxy = f32(out["xywh2xyxy"] + rs.normal(0, 40, (33, 4)))
+    det = f32(np.concatenate([xyxy, rs.uniform(0, 1, (33, 2))], 1))
+    out["scale_in"] = det
+    out["scale_a"] = y_general.scale_coords((640, 640), T(det).clone(), (720, 1280, 3)).numpy()
+    out["scale_b"] = y_general.scale_coords((384, 640), T(det).clone(), (1080, 1920)).numpy()
+    out["scale_c"] = y_general.scale_coords((640, 640), T(det).clone(), (500, 375), ratio_pad=((0.8, 0.8), (10.0, 20.0))).numpy()
+    c = T(det).clone()
+    y_general.clip_coords(c, (300, 400))
+    out["clip_t"] = c.numpy()
+    cn = det.copy()
+    y_general.clip_coords(cn, (300, 400))
+    out["clip_np"] = cn
+    save("box_utils", **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    y_metrics, y_general, y_loss, a_loss, c_loss, c_data = load_reference()
+    gen_bbox_iou(y_metrics, a_loss)
+    gen_pairwise(y_metrics)
+    gen_box_utils(y_general)
+    gen_build_targets(y_loss)
+    gen_compute_loss(y_loss)
+    gen_nms(y_general)
+    gen_centernet(a_loss, c_loss, c_data)
+
+
+if __name__ == "__main__":
+    main()
