@@ -1,0 +1,83 @@
+"""ctypes binding of libdethead.so (the C ABI declared in include/dethead.h).
+
+There is no CPU or eager-PyTorch fallback anywhere in this package: if the shared
+library is missing, or a tensor is not on a ROCm device, the call raises.
+"""
+import ctypes
+import os
+
+import torch  # imported first on purpose: libdethead must bind to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdethead.so")
+
+c_void_p, c_int, c_i64, c_double, c_float, c_size_t = (
+    ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_float, ctypes.c_size_t)
+
+ERRORS = {-1: "invalid argument (shape / null pointer / unsupported size)", -2: "HIP kernel launch failed",
+          -3: "pointer not 16-byte aligned", -4: "workspace too small"}
+
+# name -> (restype, argtypes); must list every symbol include/dethead.h declares
+SIGNATURES = {
+    "dh_bbox_iou_fwd": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_i64, c_int, c_int,
+                                c_double, c_void_p]),
+    "dh_bbox_iou_bwd": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_i64, c_i64,
+                                c_i64, c_int, c_int, c_double, c_void_p]),
+    "dh_centernet_box_loss_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "dh_centernet_box_loss_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
+                                          c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+                                          c_size_t, c_void_p]),
+    "dh_centernet_box_loss_bwd": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
+                                          c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+                                          c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
+    "dh_yolo_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                               c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libdethead.so once; raise (never fall back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C object_detection_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {ERRORS.get(rc, rc)}")
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def dev_f32(t, name="tensor"):
+    """fp32 view of a device tensor; anything not on a ROCm device is an error (no CPU path)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: object_detection_amd only runs on ROCm devices (no CPU fallback)")
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def int_array(values):
+    return (c_int * len(values))(*[int(v) for v in values])
+
+
+def float_array(values):
+    return (c_float * len(values))(*[float(v) for v in values])

@@ -1,0 +1,139 @@
+// YOLOv5 Detect head, inference branch: sigmoid + grid/anchor decode of all levels in one launch.
+//
+// Reference: object_detection/yolov5/models/yolo.py:56-70 (decode, concat) and :72-81 (_make_grid).
+//   y = sigmoid(x);  xy = (2y - 0.5 + (gx,gy)) * stride;  wh = (2y)^2 * (anchor*stride);  rest = y
+//   output row order: level, anchor, gy, gx  -> (bs, sum_l na*ny*nx, no)
+// Per image the output is one contiguous span and each level's input is one contiguous span, so
+// the kernel is a pure stream: 16-byte loads and stores, 680 B of HBM traffic per anchor, and the
+// reference's separate sigmoid / slice-assign / torch.cat passes collapse into this single pass.
+#include "dh_common.h"
+#include "../../include/dethead.h"
+
+namespace {
+
+struct decode_level {
+    const float* src;     // (bs, na, ny, nx, no) contiguous
+    uint32_t first;       // first output element of this level inside one image's span
+    uint32_t elems;       // na*ny*nx*no
+    dh_fastdiv plane;     // ny*nx
+    dh_fastdiv nx;
+    float stride;
+    float anchor_px[2 * DH_MAX_ANCHORS];   // anchors[l][a] * stride[l]  (w,h)
+};
+
+struct decode_params {
+    decode_level lvl[DH_MAX_LEVELS];
+    uint32_t blocks[DH_MAX_LEVELS];   // blocks assigned to each level along grid x
+    int nl;
+    dh_fastdiv no;
+    uint32_t per_image;   // elements of one image's output span = A*no
+};
+
+__device__ __forceinline__ float decode_one(const decode_params& P, const decode_level& L, uint32_t e, float x)
+{
+    const float s = dh_sigmoid(x);
+    const uint32_t row = dh_div(e, P.no);
+    const uint32_t c = e - row * P.no.d;
+    if (c >= 4) return s;
+    const uint32_t a = dh_div(row, L.plane);
+    const uint32_t cell = row - a * L.plane.d;
+    if (c < 2) {
+        const uint32_t gy = dh_div(cell, L.nx);
+        const uint32_t gx = cell - gy * L.nx.d;
+        const float g = (float)(c == 0 ? gx : gy);
+        return (s * 2.0f - 0.5f + g) * L.stride;
+    }
+    const float t = s * 2.0f;
+    return (t * t) * L.anchor_px[2 * a + (c - 2)];
+}
+
+// One block owns DH_DEC_UNROLL*256 consecutive vectors of ONE level of ONE image, so the level
+// record is wave-uniform (scalar registers).  VEC = 4 needs every level span to be a multiple of
+// 4 floats and 16-byte aligned; VEC = 1 is the general fallback.
+#define DH_DEC_UNROLL 4
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, float* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    int l = 0;
+    uint32_t blk = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < DH_MAX_LEVELS - 1; ++k) {
+        if (l == k && k + 1 < P.nl && blk >= P.blocks[k]) { blk -= P.blocks[k]; l = k + 1; }
+    }
+    const decode_level& L = P.lvl[l];
+    const uint32_t nvec = L.elems / VEC;
+    const float* __restrict__ src = L.src + (size_t)b * L.elems;
+    float* __restrict__ dst = out + (size_t)b * P.per_image + L.first;
+    const uint32_t v0 = blk * (256 * DH_DEC_UNROLL) + threadIdx.x;
+    if (VEC == 4) {
+        float4 x[DH_DEC_UNROLL];
+#pragma unroll
+        for (int u = 0; u < DH_DEC_UNROLL; ++u) {
+            const uint32_t v = v0 + u * 256;
+            if (v < nvec) x[u] = *reinterpret_cast<const float4*>(src + (size_t)v * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < DH_DEC_UNROLL; ++u) {
+            const uint32_t v = v0 + u * 256;
+            if (v < nvec) {
+                const uint32_t e = v * 4;
+                float4 y;
+                y.x = decode_one(P, L, e + 0, x[u].x);
+                y.y = decode_one(P, L, e + 1, x[u].y);
+                y.z = decode_one(P, L, e + 2, x[u].z);
+                y.w = decode_one(P, L, e + 3, x[u].w);
+                *reinterpret_cast<float4*>(dst + (size_t)e) = y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < DH_DEC_UNROLL; ++u) {
+            const uint32_t v = v0 + u * 256;
+            if (v < nvec) dst[v] = decode_one(P, L, v, src[v]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
+                              int no, const float* anchor_px, const float* strides, float* out, void* stream)
+{
+    if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 5 || bs < 0 || bs > 65535) return DH_ERR_ARG;
+    if (!level_ptrs || !ny || !nx || !anchor_px || !strides || (bs > 0 && !out)) return DH_ERR_ARG;
+    if (bs == 0) return DH_OK;
+    decode_params P;
+    P.nl = nl;
+    P.no = dh_make_fastdiv((uint32_t)no);
+    uint64_t first = 0;
+    bool vec4 = dh_aligned16(out);
+    for (int l = 0; l < nl; ++l) {
+        if (!level_ptrs[l] || ny[l] < 1 || nx[l] < 1) return DH_ERR_ARG;
+        const uint64_t elems = (uint64_t)na * ny[l] * nx[l] * no;
+        if (first + elems >= (1ull << 31)) return DH_ERR_ARG;   // 32-bit element indices inside one image
+        decode_level& L = P.lvl[l];
+        L.src = level_ptrs[l];
+        L.first = (uint32_t)first;
+        L.elems = (uint32_t)elems;
+        L.plane = dh_make_fastdiv((uint32_t)(ny[l] * nx[l]));
+        L.nx = dh_make_fastdiv((uint32_t)nx[l]);
+        L.stride = strides[l];
+        for (int k = 0; k < 2 * na; ++k) L.anchor_px[k] = anchor_px[l * 2 * na + k];
+        vec4 = vec4 && (elems % 4 == 0) && dh_aligned16(level_ptrs[l]);
+        first += elems;
+    }
+    P.per_image = (uint32_t)first;
+    const int vec = vec4 ? 4 : 1;
+    uint32_t gx = 0;
+    for (int l = 0; l < nl; ++l) {
+        const uint32_t nvec = P.lvl[l].elems / vec;
+        P.blocks[l] = (nvec + 256 * DH_DEC_UNROLL - 1) / (256 * DH_DEC_UNROLL);
+        gx += P.blocks[l];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (vec4) hipLaunchKernelGGL(k_yolo_decode<4>, dim3(gx, bs), dim3(256), 0, st, P, out);
+    else hipLaunchKernelGGL(k_yolo_decode<1>, dim3(gx, bs), dim3(256), 0, st, P, out);
+    return dh_launch_status();
+}

@@ -1,0 +1,64 @@
+// Shared device/host helpers for the detection-head kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DH_OK 0
+#define DH_ERR_ARG (-1)      // bad shape / null pointer / unsupported size
+#define DH_ERR_LAUNCH (-2)   // hipGetLastError() after a launch was not hipSuccess
+#define DH_ERR_ALIGN (-3)    // pointer not aligned as the kernel requires
+#define DH_ERR_WORKSPACE (-4)  // workspace too small
+
+#define DH_WAVE 64
+
+static inline int dh_launch_status() { return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH; }
+static inline bool dh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Exact unsigned division by a runtime constant for numerators < 2^31:
+// q = (n * magic) >> 32 >> shift  (round-up method).  Built on the host, used on the device.
+struct dh_fastdiv {
+    uint32_t magic;
+    uint32_t shift;
+    uint32_t d;
+};
+
+static inline dh_fastdiv dh_make_fastdiv(uint32_t d)
+{
+    dh_fastdiv f;
+    f.d = d;
+    if (d == 1) { f.magic = 0; f.shift = 0; return f; }
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;                 // l = ceil(log2 d)
+    const uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+    f.magic = (uint32_t)m;
+    f.shift = l;
+    return f;
+}
+
+// floor(n / d) for n < 2^32 (Granlund-Montgomery: t = mulhi(n,m); q = (t + ((n - t) >> 1)) >> (l-1)).
+__device__ __forceinline__ uint32_t dh_div(uint32_t n, const dh_fastdiv f)
+{
+    if (f.d == 1) return n;
+    const uint32_t t = __umulhi(n, f.magic);
+    return (t + ((n - t) >> 1)) >> (f.shift - 1);
+}
+
+__device__ __forceinline__ float dh_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ double dh_wave_sum_d(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// 1/(1+exp(-x)) with the hardware exp2/rcp units (relative error < 5e-7).
+__device__ __forceinline__ float dh_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}

@@ -1,0 +1,126 @@
+"""Drop-ins for object_detection/loss.py:102-166 (IoULossWithMask, bbox_iou on [...,4])."""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .metrics import _PairIoU, _mode
+
+_EPS = 1e-7   # default eps of loss.py:118, the only value IoULossWithMask can reach
+
+
+def bbox_iou(box1, box2, x1y1x2y2=False, GIoU=False, DIoU=False, CIoU=False, eps=1e-7):
+    """IoU family over the last dimension, centre/size boxes by default (loss.py:118-166)."""
+    b1, b2 = torch.broadcast_tensors(box1, box2)
+    lead = b1.shape[:-1]
+    out = _PairIoU.apply(b1.reshape(-1, 4), b2.reshape(-1, 4), 1, 1, x1y1x2y2, _mode(GIoU, DIoU, CIoU), eps)
+    return out.view(lead)
+
+
+def _plane_view(t, H, W):
+    """(B,2,W,H) planes usable in place: unit stride cells, contiguous planes, aligned; else a copy."""
+    ok = (t.stride(3) == 1 and t.stride(2) == H and t.stride(1) == W * H and t.stride(0) % 4 == 0
+          and t.stride(0) >= 2 * W * H and t.data_ptr() % 16 == 0)
+    return t if ok else t.contiguous()
+
+
+def _check_planes(pxy, pwh, txy, twh, m):
+    B, two, W, H = pxy.shape
+    for t in (pxy, pwh, txy, twh):
+        if tuple(t.shape) != (B, 2, W, H):
+            raise RuntimeError(f"masked CIoU loss: expected (B,2,W,H) planes like {(B, 2, W, H)}, got {tuple(t.shape)}")
+    if tuple(m.shape) != (B, W, H):
+        raise RuntimeError(f"masked CIoU loss: mask must be (B,W,H)={(B, W, H)}, got {tuple(m.shape)}")
+    if (W * H) % 4:
+        raise RuntimeError("masked CIoU loss: W*H must be a multiple of 4")
+    return B, W, H
+
+
+def _loss_forward(pxy, pwh, txy, twh, m, add_coords):
+    B, W, H = _check_planes(pxy, pwh, txy, twh, m)
+    lib = L.lib()
+    ws_bytes = lib.dh_centernet_box_loss_workspace(B, W, H)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pxy.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=pxy.device)
+    with torch.cuda.device(pxy.device):
+        L.check(lib.dh_centernet_box_loss_fwd(L.ptr(pxy), pxy.stride(0), L.ptr(pwh), pwh.stride(0), L.ptr(txy),
+                                              txy.stride(0), L.ptr(twh), twh.stride(0), L.ptr(m), B, W, H,
+                                              int(add_coords), _EPS, L.ptr(out2), L.ptr(ws), ws_bytes, L.stream()),
+                "dh_centernet_box_loss_fwd")
+    return out2
+
+
+def _loss_backward(pxy, pwh, txy, twh, m, add_coords, out2, grad_out, gxy, gwh):
+    B, _, W, H = pxy.shape
+    g = grad_out.reshape(1).float().contiguous()
+    with torch.cuda.device(pxy.device):
+        L.check(L.lib().dh_centernet_box_loss_bwd(L.ptr(pxy), pxy.stride(0), L.ptr(pwh), pwh.stride(0), L.ptr(txy),
+                                                  txy.stride(0), L.ptr(twh), twh.stride(0), L.ptr(m), B, W, H,
+                                                  int(add_coords), _EPS, L.ptr(out2), L.ptr(g), L.ptr(gxy),
+                                                  gxy.stride(0), L.ptr(gwh), gwh.stride(0), L.stream()),
+                "dh_centernet_box_loss_bwd")
+
+
+class _MaskedCIoULossPlanes(torch.autograd.Function):
+    """1 - sum(CIoU(pred*m, tgt*m)) / (4*sum(m) + 1e-4); centre and size given as separate (B,2,W,H) maps."""
+
+    @staticmethod
+    def forward(ctx, pred_xy, pred_wh, tgt_xy, tgt_wh, mask, add_coords):
+        B, _, W, H = pred_xy.shape
+        pxy, pwh, txy, twh = (_plane_view(L.dev_f32(t, n), H, W) for t, n in (
+            (pred_xy, "pred_xy"), (pred_wh, "pred_wh"), (tgt_xy, "tgt_xy"), (tgt_wh, "tgt_wh")))
+        m = L.dev_f32(mask, "mask").contiguous()
+        out2 = _loss_forward(pxy, pwh, txy, twh, m, add_coords)
+        ctx.save_for_backward(pxy, pwh, txy, twh, m, out2)
+        ctx.add_coords = bool(add_coords)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pxy, pwh, txy, twh, m, out2 = ctx.saved_tensors
+        if any(ctx.needs_input_grad[2:5]):
+            raise RuntimeError("masked CIoU loss: gradients are provided for the predictions only")
+        gxy, gwh = torch.empty_like(pxy, memory_format=torch.contiguous_format), torch.empty_like(
+            pwh, memory_format=torch.contiguous_format)
+        _loss_backward(pxy, pwh, txy, twh, m, ctx.add_coords, out2, grad_out, gxy, gwh)
+        return gxy, gwh, None, None, None, None
+
+
+class _MaskedCIoULossPacked(torch.autograd.Function):
+    """Same loss with (B,4,W,H) inputs (centre planes then size planes), as IoULossWithMask receives them."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        p = L.dev_f32(pred, "pred").contiguous()
+        t = L.dev_f32(target, "target").contiguous()
+        m = L.dev_f32(mask, "mask").contiguous()
+        if p.dim() != 4 or p.shape[1] != 4 or t.shape != p.shape:
+            raise RuntimeError(f"IoULossWithMask: expected (B,4,W,H) pred/target, got {tuple(pred.shape)} / {tuple(target.shape)}")
+        out2 = _loss_forward(p[:, 0:2], p[:, 2:4], t[:, 0:2], t[:, 2:4], m, False)
+        ctx.save_for_backward(p, t, m, out2)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        p, t, m, out2 = ctx.saved_tensors
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise RuntimeError("IoULossWithMask: gradients are provided for the predictions only")
+        grad = torch.empty_like(p)
+        _loss_backward(p[:, 0:2], p[:, 2:4], t[:, 0:2], t[:, 2:4], m, False, out2, grad_out, grad[:, 0:2], grad[:, 2:4])
+        return grad, None, None
+
+
+def masked_ciou_loss(pred_xy, pred_wh, tgt_xy, tgt_wh, mask, add_coords=False):
+    return _MaskedCIoULossPlanes.apply(pred_xy, pred_wh, tgt_xy, tgt_wh, mask, add_coords)
+
+
+class IoULossWithMask(nn.Module):
+    """loss.py:102-115.  As in the reference the constructor flags are stored but CIoU is always used."""
+
+    def __init__(self, GIoU=False, DIoU=False, CIoU=False):
+        super().__init__()
+        self.GIoU = GIoU
+        self.DIoU = DIoU
+        self.CIoU = CIoU
+
+    def forward(self, pred, target, mask):
+        return _MaskedCIoULossPacked.apply(pred, target, mask)

@@ -1,0 +1,73 @@
+"""Drop-ins for object_detection/yolov5/utils/metrics.py:201-296 (bbox_iou, box_iou, wh_iou, bbox_ioa)."""
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_MODES = {"iou": 0, "giou": 1, "diou": 2, "ciou": 3}
+
+
+def _mode(GIoU, DIoU, CIoU):
+    # precedence of metrics.py:225-239: CIoU, then DIoU, then GIoU
+    return 3 if CIoU else 2 if DIoU else 1 if GIoU else 0
+
+
+def _layout(t, comp_dim, elem_dim):
+    return t.stride(comp_dim), t.stride(elem_dim)
+
+
+class _PairIoU(torch.autograd.Function):
+    """IoU-family value of n box pairs; box tensors are 2-D with the 4 components on `comp_dim`."""
+
+    @staticmethod
+    def forward(ctx, box1, box2, comp1, comp2, xyxy, mode, eps):
+        b1, b2 = L.dev_f32(box1, "box1"), L.dev_f32(box2, "box2")
+        n = b1.shape[1 - comp1]
+        if b1.shape[comp1] != 4 or b2.shape[comp2] != 4 or b2.shape[1 - comp2] != n:
+            raise RuntimeError(f"bbox_iou: incompatible shapes {tuple(box1.shape)} and {tuple(box2.shape)}")
+        if n == 1:   # a size-1 dimension may carry any stride; normalise it
+            b1, b2 = b1.contiguous(), b2.contiguous()
+        out = torch.empty(n, dtype=torch.float32, device=b1.device)
+        s1c, s1e = _layout(b1, comp1, 1 - comp1)
+        s2c, s2e = _layout(b2, comp2, 1 - comp2)
+        with torch.cuda.device(b1.device):
+            L.check(L.lib().dh_bbox_iou_fwd(L.ptr(b1), s1c, s1e, L.ptr(b2), s2c, s2e, L.ptr(out), n, int(xyxy), mode,
+                                            float(eps), L.stream()), "dh_bbox_iou_fwd")
+        ctx.save_for_backward(b1, b2)
+        ctx.cfg = (comp1, comp2, int(xyxy), mode, float(eps), box1.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        b1, b2 = ctx.saved_tensors
+        comp1, comp2, xyxy, mode, eps, dtype = ctx.cfg
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError("bbox_iou: gradient w.r.t. box2 is not provided (the reference passes constant targets)")
+        n = b1.shape[1 - comp1]
+        g = grad_out.contiguous().float()
+        grad1 = torch.empty_like(b1)   # same strides as box1
+        s1c, s1e = _layout(b1, comp1, 1 - comp1)
+        s2c, s2e = _layout(b2, comp2, 1 - comp2)
+        sgc, sge = _layout(grad1, comp1, 1 - comp1)
+        with torch.cuda.device(b1.device):
+            L.check(L.lib().dh_bbox_iou_bwd(L.ptr(b1), s1c, s1e, L.ptr(b2), s2c, s2e, L.ptr(g), L.ptr(grad1), sgc, sge,
+                                            n, xyxy, mode, eps, L.stream()), "dh_bbox_iou_bwd")
+        return grad1.to(dtype), None, None, None, None, None, None
+
+
+def bbox_iou(box1, box2, x1y1x2y2=True, GIoU=False, DIoU=False, CIoU=False, eps=1e-7):
+    """IoU / GIoU / DIoU / CIoU of box1 (4,n) against box2 (n,4) -> (n,)  (metrics.py:201-240)."""
+    if box1.dim() == 1:
+        box1 = box1[:, None].expand(4, box2.shape[0])
+    return _PairIoU.apply(box1, box2, 0, 1, x1y1x2y2, _mode(GIoU, DIoU, CIoU), eps)
+
+
+def bbox_ioa(box1, box2, eps=1E-7):
+    """Intersection over box2 area, numpy in / numpy out (metrics.py:267-288).
+
+    Host-side by interface: its callers are the CPU augmentation code that works on numpy labels.
+    """
+    box2 = box2.transpose()
+    iw = (np.minimum(box1[2], box2[2]) - np.maximum(box1[0], box2[0])).clip(0)
+    ih = (np.minimum(box1[3], box2[3]) - np.maximum(box1[1], box2[1])).clip(0)
+    return iw * ih / ((box2[2] - box2[0]) * (box2[3] - box2[1]) + eps)

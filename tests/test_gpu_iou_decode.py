@@ -1,0 +1,195 @@
+"""GPU parity: IoU family (value + gradient), CenterNet masked CIoU loss, YOLO decode.
+
+Float tolerance: 1e-5 relative (the bar for IoU / loss / gradients in fp32), with an absolute
+floor of 1e-6 x the largest magnitude in the compared tensor for gradient entries that are sums
+of cancelling terms.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import centernet as oc
+from oracle import yolo as oy
+from tests._synth import synth_head
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+MODE_FLAGS = {"iou": {}, "giou": {"GIoU": True}, "diou": {"DIoU": True}, "ciou": {"CIoU": True}}
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def close(got, want, rtol=RTOL, floor=1e-6):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    scale = float(np.abs(want).max()) if want.size else 0.0
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=floor * max(scale, 1e-30))
+
+
+@pytest.mark.parametrize("tag", ["n1", "n257", "n2048", "special"])
+@pytest.mark.parametrize("fmt", ["xywh", "xyxy"])
+@pytest.mark.parametrize("mode", list(MODE_FLAGS))
+def test_bbox_iou_yolo_layout(golden, tag, fmt, mode):
+    from object_detection_amd.metrics import bbox_iou
+    g = golden("bbox_iou")
+    b1 = T(g[f"{tag}_{fmt}_box1"]).cuda().T.requires_grad_(True)       # (4,n) view of (n,4) rows, as loss.py:135
+    val = bbox_iou(b1, T(g[f"{tag}_{fmt}_box2"]).cuda(), x1y1x2y2=(fmt == "xyxy"), **MODE_FLAGS[mode])
+    grad, = torch.autograd.grad(val.sum(), b1)
+    close(val, g[f"{tag}_{fmt}_{mode}_out"])
+    close(grad, g[f"{tag}_{fmt}_{mode}_grad"])
+    # planar (4,n) contiguous layout as well
+    b1c = T(g[f"{tag}_{fmt}_box1"]).T.contiguous().cuda().requires_grad_(True)
+    val2 = bbox_iou(b1c, T(g[f"{tag}_{fmt}_box2"]).cuda(), x1y1x2y2=(fmt == "xyxy"), **MODE_FLAGS[mode])
+    grad2, = torch.autograd.grad((val2 * 2.0).sum(), b1c)
+    assert torch.equal(val2, val)
+    close(grad2, 2.0 * g[f"{tag}_{fmt}_{mode}_grad"])
+
+
+def test_bbox_iou_lastdim_layout(golden):
+    from object_detection_amd.loss import bbox_iou
+    g = golden("bbox_iou")
+    for mode, flags in MODE_FLAGS.items():
+        b1 = T(g["lastdim_box1"]).cuda().requires_grad_(True)
+        val = bbox_iou(b1, T(g["lastdim_box2"]).cuda(), **flags)
+        grad, = torch.autograd.grad(val.sum(), b1)
+        assert val.shape == (3, 20)
+        close(val, g[f"lastdim_{mode}_out"])
+        close(grad, g[f"lastdim_{mode}_grad"])
+
+
+def test_bbox_iou_large_random_vs_oracle():
+    """300k random pairs.  Values: 1e-5 relative to the fp32 oracle.  Gradients: an fp32 gradient is a
+    sum of cancelling terms, so two correct fp32 evaluations in different operation order can differ by
+    more than 1e-5 of the result on ill-conditioned pairs; there the HIP result must be as close to the
+    float64 evaluation of the same formula as the fp32 oracle itself is (within a factor 4)."""
+    from object_detection_amd.metrics import bbox_iou
+    rs = np.random.RandomState(3)
+    n = 300_001
+    p = np.concatenate([rs.uniform(0, 80, (n, 2)), np.exp(rs.uniform(-2, 4, (n, 2)))], 1).astype(np.float32)
+    t = (p + rs.normal(0, 1.0, (n, 4))).astype(np.float32)
+    t[:, 2:] = np.abs(t[:, 2:])
+    for mode, flags in MODE_FLAGS.items():
+        b1 = T(p).T.contiguous().requires_grad_(True)
+        want = ob.bbox_iou_yolo(b1, T(t), x1y1x2y2=False, **flags)
+        wg, = torch.autograd.grad(want.sum(), b1)
+        b64 = T(p).double().T.contiguous().requires_grad_(True)
+        w64 = ob.bbox_iou_yolo(b64, T(t).double(), x1y1x2y2=False, **flags)
+        g64, = torch.autograd.grad(w64.sum(), b64)
+        d1 = T(p).cuda().T.requires_grad_(True)
+        got = bbox_iou(d1, T(t).cuda(), x1y1x2y2=False, **flags)
+        gg, = torch.autograd.grad(got.sum(), d1)
+        close(got, want.detach())
+        gw, gg, g64 = wg.numpy(), gg.cpu().numpy(), g64.numpy()
+        scale = np.abs(g64).max(0, keepdims=True) + 1e-12
+        err_hip = np.abs(gg - g64) / scale
+        err_ref = np.abs(gw - g64) / scale
+        assert np.all(err_hip <= 1e-5 + 4 * err_ref), (mode, float(err_hip.max()), float(err_ref.max()))
+        assert np.mean(np.abs(gg - gw) / scale > 1e-5) < 1e-3, mode     # and nearly all agree to 1e-5 directly
+
+
+@pytest.mark.parametrize("tag", ["pos", "zero", "dense"])
+def test_centernet_box_loss(golden, tag):
+    from object_detection_amd.centernet import compute_losses
+    from object_detection_amd.loss import IoULossWithMask
+    g = golden("centernet")
+    ps = T(g["loss_pred_size"]).cuda().requires_grad_(True)
+    po = T(g["loss_pred_offset"]).cuda().requires_grad_(True)
+    losses = {}
+    crit = {"cls": lambda a, b: torch.zeros((), device="cuda"), "box": IoULossWithMask(CIoU=True), "size": None, "offset": None}
+    compute_losses([T(g["loss_pred_cls"]).cuda(), ps, po],
+                   [T(g["loss_lab_cls"]).cuda(), T(g["loss_lab_size"]).cuda(), T(g["loss_lab_offset"]).cuda(),
+                    T(g[f"loss_{tag}_mask"]).cuda()], crit, losses)
+    gs, go = torch.autograd.grad(losses["box"] * 3.0, [ps, po])
+    close(losses["box"], g[f"loss_{tag}_value"])
+    close(gs, 3.0 * g[f"loss_{tag}_grad_size"])
+    close(go, 3.0 * g[f"loss_{tag}_grad_offset"])
+    if tag == "zero":
+        assert float(losses["box"]) == 1.0
+
+
+def test_iou_loss_with_mask_direct(golden):
+    from object_detection_amd.centernet import offset_to_coord
+    from object_detection_amd.loss import IoULossWithMask
+    g = golden("centernet")
+    close(offset_to_coord(T(g["loss_pred_offset"]).cuda()), g["offset_to_coord"], 0, 0)
+    p = T(g["direct_pred"]).cuda().requires_grad_(True)
+    val = IoULossWithMask(GIoU=True)(p, T(g["direct_target"]).cuda(), T(g["direct_mask"]).cuda())
+    grad, = torch.autograd.grad(val, p)
+    close(val, g["direct_value"])
+    close(grad, g["direct_grad"])
+
+
+def test_centernet_loss_full_size_vs_oracle():
+    """bs 16 x 160x160 maps (stride-4 grid of a 640 px input), sparse mask."""
+    from object_detection_amd.loss import masked_ciou_loss
+    rs = np.random.RandomState(9)
+    B, W, H = 16, 160, 160
+    mask = (rs.uniform(0, 1, (B, W, H)) < 0.01).astype(np.float32)
+    lab_size = (np.abs(rs.normal(8, 4, (B, 2, W, H))) * mask[:, None]).astype(np.float32)
+    lab_off = (rs.uniform(0, 1, (B, 2, W, H)) * mask[:, None]).astype(np.float32)
+    pred_size = np.abs(lab_size + rs.normal(0, 2, lab_size.shape)).astype(np.float32)
+    pred_off = rs.uniform(0, 1, lab_off.shape).astype(np.float32)
+    ps, po = T(pred_size).requires_grad_(True), T(pred_off).requires_grad_(True)
+    want = oc.box_loss([None, ps, po], [None, T(lab_size), T(lab_off), T(mask)])
+    ws, wo = torch.autograd.grad(want, [ps, po])
+    dps, dpo = T(pred_size).cuda().requires_grad_(True), T(pred_off).cuda().requires_grad_(True)
+    got = masked_ciou_loss(dpo, dps, T(lab_off).cuda(), T(lab_size).cuda(), T(mask).cuda(), add_coords=True)
+    gs, go = torch.autograd.grad(got, [dps, dpo])
+    close(got, want.detach())
+    close(gs, ws)
+    close(go, wo)
+    # size-independent property: an all-zero mask gives exactly 1 and zero gradients
+    z = torch.zeros_like(T(mask)).cuda()
+    got0 = masked_ciou_loss(dpo, dps, T(lab_off).cuda(), T(lab_size).cuda(), z, add_coords=True)
+    g0s, g0o = torch.autograd.grad(got0, [dps, dpo])
+    assert float(got0) == 1.0 and float(g0s.abs().max()) == 0.0 and float(g0o.abs().max()) == 0.0
+
+
+def _decode_case(bs, img, nc, seed, strides=(8, 16, 32)):
+    from object_detection_amd.yolo import detect_decode
+    rs = np.random.RandomState(seed)
+    levels = synth_head(rs, bs, img, nc, strides)
+    anchors = oy.grid_anchors()
+    want = oy.detect_decode([T(x) for x in levels], anchors, oy.YOLOV5S_STRIDES)
+    got = detect_decode([T(x).cuda() for x in levels], anchors.cuda(), torch.tensor(oy.YOLOV5S_STRIDES))
+    assert got.shape == want.shape
+    close(got, want)
+
+
+def test_decode_small_cases():
+    _decode_case(2, 64, 80, 1)      # 8/4/2 grids
+    _decode_case(3, 96, 7, 2)       # no = 12
+    _decode_case(1, 32, 2, 3)       # no = 7: level spans not multiples of 4 -> scalar path
+
+
+def test_decode_bs8_640_vs_oracle():
+    _decode_case(8, 640, 80, 4)
+
+
+def test_decode_identity_with_training_decode():
+    """inference decode == (training decode of loss.py:132-133 + grid) * stride, a size-independent identity."""
+    from object_detection_amd.yolo import detect_decode
+    rs = np.random.RandomState(5)
+    bs, img, nc = 64, 640, 80
+    anchors = oy.grid_anchors()
+    x = [torch.from_numpy(v).cuda() for v in synth_head(rs, bs, img, nc)]
+    got = detect_decode(x, anchors.cuda(), torch.tensor(oy.YOLOV5S_STRIDES))
+    first = 0
+    for lvl, xl in enumerate(x):
+        _, na, ny, nx, no = xl.shape
+        s = xl.sigmoid()
+        gy, gx = torch.meshgrid(torch.arange(ny, device="cuda"), torch.arange(nx, device="cuda"), indexing="ij")
+        grid = torch.stack((gx, gy), 2).view(1, 1, ny, nx, 2).float()
+        pxy = (s[..., :2] * 2 - 0.5 + grid) * oy.YOLOV5S_STRIDES[lvl]
+        pwh = (s[..., 2:4] * 2) ** 2 * (anchors[lvl].cuda() * oy.YOLOV5S_STRIDES[lvl]).view(1, na, 1, 1, 2)
+        want = torch.cat((pxy, pwh, s[..., 4:]), -1).view(bs, -1, no)
+        n = want.shape[1]
+        # xy = (2s - 0.5 + g) * stride cancels near the cell origin, so its error is bounded in
+        # pixels (1e-5 of the stride-scaled term), not relative to the possibly tiny result
+        torch.testing.assert_close(got[:, first:first + n], want, rtol=RTOL, atol=1e-5 * oy.YOLOV5S_STRIDES[lvl])
+        first += n
+    assert first == got.shape[1] == 25200
