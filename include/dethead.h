@@ -66,6 +66,38 @@ int dh_centernet_box_loss_bwd(const float* pred_xy, int64_t pred_xy_bstride, con
 int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
                    const float* anchor_px, const float* strides, float* out, void* stream);
 
+/* Batched non_max_suppression (object_detection/yolov5/utils/general.py:647-738) over
+ * pred (bs, A, 5+nc) = [x,y,w,h,obj,cls...].  Output rows are [x1,y1,x2,y2,conf,cls] in the
+ * reference's order (score descending; equal scores in candidate order), out is (bs,max_det,6),
+ * out_count (bs) the rows valid per image, cand_count (bs) the candidates found per image:
+ * cand_count[b] > cap means the per-image candidate capacity overflowed and the call must be
+ * repeated with a larger cap (only possible with multi_label; cap = A always suffices otherwise).
+ * class_keep: nc bytes on the device (1 = keep class) or NULL (general.py:705-706).
+ * max_nms = 30000 and max_wh = 7680 in the reference (general.py:663-664).  All of out,
+ * out_count, cand_count, workspace are device memory; workspace must be 256-byte aligned. */
+size_t dh_nms_workspace(int bs, int cap, int max_nms);
+int dh_nms_batched(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres, int multi_label,
+                   int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+                   float* out, int* out_count, int* cand_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* torchvision.ops.nms(boxes[n,4] xyxy, scores[n], iou_threshold) as called at
+ * object_detection/yolov5/utils/general.py:722 and object_detection/detectors/centernet/dataset.py:263:
+ * keep_index (n int64, device) receives the kept original indices in score-descending order
+ * (equal scores: ascending index), keep_count (1 int, device) how many. */
+size_t dh_nms_plain_workspace(int64_t n);
+int dh_nms_plain(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
+                 int* keep_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* xywh2xyxy (mode 0) / xyxy2xywh (mode 1) on the first four columns of n rows
+ * (object_detection/yolov5/utils/general.py:543-560); strides in floats; in == out is allowed. */
+int dh_box_convert(const float* in, int64_t in_row_stride, float* out, int64_t out_row_stride, int64_t n, int mode,
+                   void* stream);
+
+/* In-place scale_coords (do_scale != 0: (v - pad)/gain, then clip) or clip_coords (do_scale == 0)
+ * on the first four columns of n rows (general.py:619-644).  max_x/max_y = image width/height. */
+int dh_scale_clip_coords(float* boxes, int64_t row_stride, int64_t n, int do_scale, double pad_x, double pad_y,
+                         double gain, double max_x, double max_y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,14 @@ SIGNATURES = {
                                           c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
     "dh_yolo_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p]),
+    "dh_nms_workspace": (c_size_t, [c_int, c_int, c_int]),
+    "dh_nms_batched": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p, c_int, c_int,
+                               c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_nms_plain_workspace": (c_size_t, [c_i64]),
+    "dh_nms_plain": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_box_convert": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p]),
+    "dh_scale_clip_coords": (c_int, [c_void_p, c_i64, c_i64, c_int, c_double, c_double, c_double, c_double, c_double,
+                                     c_void_p]),
 }
 
 _lib = None
@@ -73,6 +81,11 @@ def dev_f32(t, name="tensor"):
     if not t.is_cuda:
         raise RuntimeError(f"{name} is on {t.device}: object_detection_amd only runs on ROCm devices (no CPU fallback)")
     return t if t.dtype == torch.float32 else t.float()
+
+
+def workspace(nbytes, device):
+    """256-byte aligned scratch from torch's caching allocator."""
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
 
 
 def int_array(values):

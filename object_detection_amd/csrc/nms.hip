@@ -1,0 +1,650 @@
+// Batched class-aware NMS + top-k for YOLOv5-style predictions, and a plain nms(boxes, scores, thr).
+//
+// Reference behaviour:
+//   object_detection/yolov5/utils/general.py:647-738  non_max_suppression (filter, conf = obj*cls,
+//       xywh->xyxy, best-class / multi-label, class filter, top-30000, class-offset boxes, nms, max_det)
+//   torchvision.ops.nms 0.11.1 (third party; called at general.py:722 and
+//       object_detection/detectors/centernet/dataset.py:263): greedy, strict ">" against the double
+//       threshold, fp32 areas / intersection / division, result in score-descending order.
+//
+// Pipeline (every stage is one launch over the whole batch; nothing returns to the host):
+//   1 prefilter   wave-per-64-rows scan of the objectness column, ballot of candidates, cooperative
+//                 row loads only for candidates, emits one 64-bit key per detection:
+//                 [~order(score) : 32 | anchor*nc + class : 32]  -> ascending key order is
+//                 "score descending, then reference candidate order", i.e. the stable refinement
+//                 of the reference's unstable sorts, independent of the emission order.
+//   2 sort        per-image bitonic sort of the keys (LDS resident up to 8192 keys, global+LDS beyond)
+//   3 gather      rank -> box corners / conf / class rows, second key [class : 32 | rank : 32]
+//   4 sort        per-image sort by (class, rank): each class becomes a contiguous, score-ordered segment
+//   5 greedy      one workgroup per (class, image) segment: 64 candidates at a time are tested against
+//                 the kept list (LDS, split across waves) and then resolved inside the chunk with
+//                 ballot masks by one wave; boxes carry the reference's fp32 class offset so the IoUs
+//                 are bit-identical; stops at max_det kept per segment
+//   6 collect     ballot/prefix-scan compaction of kept ranks in rank order, first max_det rows out
+// Cross-class pairs are skipped only when the image's coordinate range proves they cannot intersect
+// after the 7680-px class offset; otherwise that image is handled as one segment with per-box offsets.
+#include "dh_common.h"
+#include "../../include/dethead.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+#define SORT_THREADS 1024
+#define SORT_LDS_KEYS 8192
+#define KEY_SENTINEL 0xFFFFFFFFFFFFFFFFull
+#define STAGE_KEYS 512
+#define KEPT_LDS 1024
+
+// monotone map float -> uint32 (ascending), inverted so that ascending keys mean descending scores
+__device__ __forceinline__ uint32_t score_key(float s)
+{
+    const uint32_t b = __float_as_uint(s);
+    const uint32_t e = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    return ~e;
+}
+
+__device__ __forceinline__ float key_score(uint32_t k)
+{
+    const uint32_t e = ~k;
+    const uint32_t b = (e & 0x80000000u) ? (e ^ 0x80000000u) : ~e;
+    return __uint_as_float(b);
+}
+
+__device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+
+// ------------------------------------------------------------------------------------------ 1 prefilter
+struct row_best {
+    float v;
+    int c;
+};
+
+__device__ __forceinline__ row_best wave_argmax_first(float v, int c)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oc = __shfl_xor(c, o, 64);
+        if (ov > v || (ov == v && oc < c)) { v = ov; c = oc; }
+    }
+    row_best r = {v, c};
+    return r;
+}
+
+template <bool MULTI>
+__global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__ pred, int A, int nc, float conf,
+                                                       const unsigned char* __restrict__ class_keep, int cap,
+                                                       u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
+{
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int no = nc + 5;
+    const float* __restrict__ img = pred + (size_t)b * A * no;
+    u64* __restrict__ out = keys + (size_t)b * cap_pad;
+    __shared__ u64 stage[4][STAGE_KEYS];
+    int pending = 0;
+
+    for (int row0 = (blockIdx.x * 4 + wave) * 64; row0 < A; row0 += gridDim.x * 256) {
+        const int row = row0 + lane;
+        const float obj = (row < A) ? img[(size_t)row * no + 4] : 0.0f;
+        const bool cand = (row < A) && (obj > conf);                       // general.py:656,675
+        u64 todo = __ballot(cand);
+        float my_best = 0.0f;
+        int my_cls = 0;
+        while (todo) {
+            // up to 4 candidate rows in flight per wave
+            int r[4];
+            float o[4];
+            int nr = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (todo) {
+                    r[k] = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    nr = k + 1;
+                } else {
+                    r[k] = r[0];
+                }
+                o[k] = __shfl(obj, r[k], 64);
+            }
+            float bv[4];
+            int bc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { bv[k] = -INFINITY; bc[k] = 0x7fffffff; }
+            for (int c0 = 0; c0 < nc; c0 += 64) {
+                const int c = c0 + lane;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    v[k] = (c < nc) ? img[(size_t)(row0 + r[k]) * no + 5 + c] : 0.0f;
+                const bool keepc = (c < nc) && (class_keep == nullptr || class_keep[c] != 0);   // general.py:705-706
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float s = v[k] * o[k];                                               // general.py:691
+                    if (MULTI) {
+                        const bool pass = (k < nr) && keepc && (s > conf);                     // general.py:698
+                        const u64 pm = __ballot(pass);
+                        if (pm) {
+                            if (pass) {
+                                const int slot = pending + __popcll(pm & lanemask_lt());
+                                stage[wave][slot] = ((u64)score_key(s) << 32) | (uint32_t)((row0 + r[k]) * nc + c);
+                            }
+                            pending += __popcll(pm);
+                        }
+                    } else if (c < nc && s > bv[k]) {
+                        bv[k] = s;
+                        bc[k] = c;
+                    }
+                }
+                if (MULTI && pending > STAGE_KEYS - 4 * 64) {   // flush: one atomic per >256 keys; 256 more always fit
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&counts[b], pending);
+                    base = __shfl(base, 0, 64);
+                    for (int i = lane; i < pending; i += 64)
+                        if (base + i < cap) out[base + i] = stage[wave][i];
+                    pending = 0;
+                }
+            }
+            if (!MULTI) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const row_best rb = wave_argmax_first(bv[k], bc[k]);                       // general.py:701 (first max)
+                    if (k < nr && lane == r[k]) { my_best = rb.v; my_cls = rb.c; }
+                }
+            }
+        }
+        if (!MULTI) {
+            const bool pass = cand && (my_best > conf) && (class_keep == nullptr || class_keep[my_cls] != 0);
+            const u64 pm = __ballot(pass);
+            if (pm) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&counts[b], __popcll(pm));
+                base = __shfl(base, 0, 64);
+                const int slot = base + __popcll(pm & lanemask_lt());
+                if (pass && slot < cap) out[slot] = ((u64)score_key(my_best) << 32) | (uint32_t)(row * nc + my_cls);
+            }
+        }
+    }
+    if (MULTI && pending) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&counts[b], pending);
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < pending; i += 64)
+            if (base + i < cap) out[base + i] = stage[wave][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 2/4 sort
+__device__ __forceinline__ void cmpswap(u64& a, u64& b, bool ascending)
+{
+    if ((a > b) == ascending) { const u64 t = a; a = b; b = t; }
+}
+
+// all (k, j) steps of the bitonic network with j < chunk, on `chunk` keys held in LDS;
+// `gbase` is the global position of s[0] (it fixes the direction bits for k > chunk).
+__device__ void bitonic_lds(u64* s, uint32_t chunk, uint32_t gbase, uint32_t k_first, uint32_t k_last)
+{
+    for (uint32_t k = k_first; k <= k_last; k <<= 1) {
+        for (uint32_t j = (k >> 1) < chunk ? (k >> 1) : (chunk >> 1); j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < chunk / 2; t += blockDim.x) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t l = i | j;
+                const bool asc = ((gbase + i) & k) == 0;
+                u64 a = s[i], c = s[l];
+                if ((a > c) == asc) { s[i] = c; s[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t pow2_ceil(uint32_t n)
+{
+    uint32_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+// One workgroup sorts one image's keys ascending.  n = min(counts[b], limit).
+__global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ keys_all, const int* __restrict__ counts,
+                                                            int limit, int cap_pad)
+{
+    __shared__ u64 s[SORT_LDS_KEYS];
+    u64* __restrict__ keys = keys_all + (size_t)blockIdx.x * cap_pad;
+    int n = counts[blockIdx.x];
+    if (n > limit) n = limit;
+    if (n <= 1) return;
+    const uint32_t npad = pow2_ceil((uint32_t)n);
+    if (npad <= SORT_LDS_KEYS) {
+        for (uint32_t i = threadIdx.x; i < npad; i += blockDim.x) s[i] = (i < (uint32_t)n) ? keys[i] : KEY_SENTINEL;
+        __syncthreads();
+        bitonic_lds(s, npad, 0, 2, npad);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += blockDim.x) keys[i] = s[i];
+        return;
+    }
+    // larger than LDS: pad in global memory, sort LDS-sized chunks, then merge with global steps + LDS tails
+    for (uint32_t i = n + threadIdx.x; i < npad; i += blockDim.x) keys[i] = KEY_SENTINEL;
+    __syncthreads();
+    for (uint32_t base = 0; base < npad; base += SORT_LDS_KEYS) {
+        for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) s[i] = keys[base + i];
+        __syncthreads();
+        bitonic_lds(s, SORT_LDS_KEYS, base, 2, SORT_LDS_KEYS);
+        for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) keys[base + i] = s[i];
+        __syncthreads();
+    }
+    for (uint32_t k = 2 * SORT_LDS_KEYS; k <= npad; k <<= 1) {
+        for (uint32_t j = k >> 1; j >= SORT_LDS_KEYS; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < npad / 2; t += blockDim.x) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const uint32_t l = i | j;
+                const bool asc = (i & k) == 0;
+                const u64 a = keys[i], c = keys[l];
+                if ((a > c) == asc) { keys[i] = c; keys[l] = a; }
+            }
+            __syncthreads();   // one workgroup owns the image: its own global writes are visible to it after the barrier
+        }
+        for (uint32_t base = 0; base < npad; base += SORT_LDS_KEYS) {
+            for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) s[i] = keys[base + i];
+            __syncthreads();
+            bitonic_lds(s, SORT_LDS_KEYS, base, k, k);
+            for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) keys[base + i] = s[i];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 3 gather
+__device__ __forceinline__ int float_order(float f)   // monotone float -> int for atomicMin/Max
+{
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : (i ^ 0x7fffffff);
+}
+__device__ __forceinline__ float order_float(int i) { return __int_as_float(i >= 0 ? i : (i ^ 0x7fffffff)); }
+
+struct img_range {   // per image: coordinate range of the boxes that reach NMS (+ a not-finite flag)
+    int lo, hi, bad, pad;
+};
+
+__global__ void __launch_bounds__(256) k_nms_gather(const float* __restrict__ pred, int A, dh_fastdiv ncd,
+                                                    const u64* __restrict__ keys, int cap_pad,
+                                                    const int* __restrict__ counts, int cap, int max_nms,
+                                                    float* __restrict__ det, u64* __restrict__ keys2, int m_pad,
+                                                    int m_cap, img_range* __restrict__ range)
+{
+    const int b = blockIdx.y;
+    int n = counts[b];
+    if (n > cap) n = cap;
+    const int m = n < max_nms ? n : max_nms;                                        // general.py:716-717
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int no = (int)ncd.d + 5;
+    float lo = INFINITY, hi = -INFINITY;
+    bool bad = false;
+    if (r < m) {
+        const u64 key = keys[(size_t)b * cap_pad + r];
+        const uint32_t ord = (uint32_t)key;
+        const uint32_t anchor = dh_div(ord, ncd);
+        const uint32_t cls = ord - anchor * ncd.d;
+        const float* __restrict__ p = pred + ((size_t)b * A + anchor) * no;
+        const float x = p[0], y = p[1], w = p[2], h = p[3];
+        const float x1 = x - w / 2, y1 = y - h / 2, x2 = x + w / 2, y2 = y + h / 2;     // general.py:553-560
+        float* __restrict__ d = det + ((size_t)b * m_cap + r) * 6;
+        d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2;
+        d[4] = key_score((uint32_t)(key >> 32));
+        d[5] = (float)cls;
+        keys2[(size_t)b * m_pad + r] = ((u64)cls << 32) | (uint32_t)r;
+        lo = fminf(fminf(x1, y1), fminf(x2, y2));
+        hi = fmaxf(fmaxf(x1, y1), fmaxf(x2, y2));
+        bad = !(fabsf(x1) < 1e30f && fabsf(y1) < 1e30f && fabsf(x2) < 1e30f && fabsf(y2) < 1e30f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    }
+    const u64 anybad = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && blockIdx.x * blockDim.x + (threadIdx.x & ~63) < m) {
+        if (lo <= hi) {
+            atomicMin(&range[b].lo, float_order(lo));
+            atomicMax(&range[b].hi, float_order(hi));
+        }
+        if (anybad) atomicOr(&range[b].bad, 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 5 greedy
+struct box_t {
+    float x1, y1, x2, y2;
+};
+
+// suppress iff inter/(area_a + area_b - inter) > thr, evaluated exactly as the fp32 reference does;
+// `thr` is the largest float <= the double threshold, which makes the fp32 ">" equal to the
+// reference's comparison in double.  inter == 0 can never exceed a threshold >= 0, so the division
+// is only evaluated for overlapping pairs.
+__device__ __forceinline__ bool suppresses(const box_t a, float area_a, const box_t b, float area_b, float thr)
+{
+    const float w = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.0f);
+    const float h = fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.0f);
+    const float inter = w * h;
+    if (!(inter > 0.0f)) return false;
+    return __fdiv_rn(inter, area_a + area_b - inter) > thr;
+}
+
+__device__ __forceinline__ int lower_bound_key(const u64* __restrict__ k, int n, u64 v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (k[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// WAVES waves per workgroup.  grid = (number of classes or 1, images).
+//   class mode: block (c, b) owns the positions of class c in keys2 (sorted by class, then rank);
+//   whole mode (agnostic, or an image whose coordinate range does not rule out cross-class overlap):
+//   block (0, b) owns ranks 0..m-1 in rank order, each box shifted by its own class offset.
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restrict__ det, const u64* __restrict__ keys2,
+                                                           int m_pad, int m_cap, const int* __restrict__ counts,
+                                                           int cap, int max_nms, const img_range* __restrict__ range,
+                                                           int agnostic, float max_wh, float thr, int max_det,
+                                                           unsigned char* __restrict__ keep, float4* __restrict__ kept_spill)
+{
+    const int b = blockIdx.y;
+    int n = counts[b];
+    if (n > cap) n = cap;
+    const int m = n < max_nms ? n : max_nms;
+    if (m == 0) return;
+    bool whole = agnostic != 0;
+    if (!whole) {
+        const img_range rg = range[b];
+        const float lo = order_float(rg.lo), hi = order_float(rg.hi);
+        whole = rg.bad != 0 || !(hi - lo < max_wh - 1.0f);
+    }
+    int s, e;
+    const u64* __restrict__ k2 = keys2 + (size_t)b * m_pad;
+    if (whole) {
+        if (blockIdx.x != 0) return;
+        s = 0; e = m;
+    } else {
+        s = lower_bound_key(k2, m, (u64)blockIdx.x << 32);
+        e = lower_bound_key(k2, m, ((u64)blockIdx.x + 1) << 32);
+        if (s >= e) return;
+    }
+    const float* __restrict__ dimg = det + (size_t)b * m_cap * 6;
+    unsigned char* __restrict__ kimg = keep + (size_t)b * m_cap;
+    float4* __restrict__ spill = kept_spill + (size_t)b * m_cap + s;   // kept boxes of this segment beyond the LDS part
+
+    __shared__ float4 kbox[KEPT_LDS];
+    __shared__ float karea[KEPT_LDS];
+    __shared__ u64 sup_mask[WAVES];
+    __shared__ int s_kept;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float off_scale = agnostic ? 0.0f : max_wh;
+    int kept = 0;
+
+    for (int base = s; base < e && kept < max_det; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < e;
+        int rank = 0;
+        box_t bx = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            rank = whole ? p : (int)(uint32_t)k2[p];
+            const float* __restrict__ d = dimg + (size_t)rank * 6;
+            const float c = d[5] * off_scale;                                     // general.py:720
+            bx.x1 = d[0] + c; bx.y1 = d[1] + c; bx.x2 = d[2] + c; bx.y2 = d[3] + c;   // general.py:721
+        }
+        const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
+        // phase 1: against everything kept so far, kept list split across the waves
+        bool sup = false;
+        for (int k = wave; k < kept; k += WAVES) {
+            float4 kb;
+            float ka;
+            if (k < KEPT_LDS) { kb = kbox[k]; ka = karea[k]; }
+            else { kb = spill[k]; ka = (kb.z - kb.x) * (kb.w - kb.y); }
+            const box_t kbb = {kb.x, kb.y, kb.z, kb.w};
+            sup = sup || suppresses(kbb, ka, bx, area, thr);
+        }
+        const u64 sm = __ballot(sup);
+        if (lane == 0) sup_mask[wave] = sm;
+        __syncthreads();
+        // phase 2: wave 0 resolves the chunk in score order with ballot masks
+        if (wave == 0) {
+            u64 dead = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) dead |= sup_mask[w];
+            u64 todo = __ballot(valid) & ~dead;
+            while (todo && kept < max_det) {
+                const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+                todo &= todo - 1;
+                box_t bi;
+                bi.x1 = __shfl(bx.x1, i, 64); bi.y1 = __shfl(bx.y1, i, 64);
+                bi.x2 = __shfl(bx.x2, i, 64); bi.y2 = __shfl(bx.y2, i, 64);
+                const float ai = __shfl(area, i, 64);
+                const bool hit = (lane > i) && suppresses(bi, ai, bx, area, thr);
+                todo &= ~__ballot(hit);
+                if (lane == i) {
+                    kimg[rank] = 1;
+                    const float4 v = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+                    if (kept < KEPT_LDS) { kbox[kept] = v; karea[kept] = area; }
+                    else spill[kept] = v;
+                }
+                ++kept;
+            }
+            if (lane == 0) s_kept = kept;
+            __threadfence_block();
+        }
+        __syncthreads();
+        kept = s_kept;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 6 collect
+// First max_det kept ranks (ascending rank == descending score) -> out rows (or original indices).
+__global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ det, const unsigned char* __restrict__ keep,
+                                                      const u64* __restrict__ keys, int cap_pad, int m_cap,
+                                                      const int* __restrict__ counts, int cap, int max_nms, int max_det,
+                                                      float* __restrict__ out, long long* __restrict__ out_index,
+                                                      int* __restrict__ out_count)
+{
+    const int b = blockIdx.x;
+    int n = counts[b];
+    if (n > cap) n = cap;
+    const int m = n < max_nms ? n : max_nms;
+    __shared__ int wcount[16];
+    __shared__ int s_total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int total = 0;
+    for (int base = 0; base < m && total < max_det; base += 1024) {
+        const int r = base + threadIdx.x;
+        const bool k = r < m && keep[(size_t)b * m_cap + r] != 0;
+        const u64 bm = __ballot(k);
+        if (lane == 0) wcount[wave] = __popcll(bm);
+        __syncthreads();
+        int before = 0, all = 0;
+        for (int w = 0; w < 16; ++w) { const int c = wcount[w]; if (w < wave) before += c; all += c; }
+        const int pos = total + before + __popcll(bm & lanemask_lt());
+        if (k && pos < max_det) {
+            if (out) {
+                const float* __restrict__ d = det + ((size_t)b * m_cap + r) * 6;
+                float* __restrict__ o = out + ((size_t)b * max_det + pos) * 6;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) o[q] = d[q];
+            }
+            if (out_index) out_index[(size_t)b * max_det + pos] = (long long)(uint32_t)keys[(size_t)b * cap_pad + r];
+        }
+        total += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_count[b] = total < max_det ? total : max_det;
+}
+
+// plain nms(): keys from scores, det rows from boxes
+__global__ void __launch_bounds__(256) k_nms_plain_keys(const float* __restrict__ scores, int n, u64* __restrict__ keys,
+                                                        int* __restrict__ counts)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ((u64)score_key(scores[i]) << 32) | (uint32_t)i;
+    if (i == 0) counts[0] = n;
+}
+
+__global__ void __launch_bounds__(256) k_nms_plain_gather(const float* __restrict__ boxes, const u64* __restrict__ keys,
+                                                          int n, float* __restrict__ det)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const u64 key = keys[r];
+    const float* __restrict__ p = boxes + (size_t)(uint32_t)key * 4;
+    float* __restrict__ d = det + (size_t)r * 6;
+    d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; d[3] = p[3];
+    d[4] = key_score((uint32_t)(key >> 32));
+    d[5] = 0.0f;
+}
+
+struct nms_layout {
+    int cap_pad, m_cap, m_pad;
+    size_t off_counts, off_range, off_keys, off_keys2, off_det, off_keep, off_spill, total;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+uint32_t pow2_ceil_host(uint32_t n)
+{
+    uint32_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+nms_layout make_layout(int bs, int cap, int max_nms)
+{
+    nms_layout L;
+    L.cap_pad = (int)pow2_ceil_host((uint32_t)(cap < 2 ? 2 : cap));
+    L.m_cap = cap < max_nms ? cap : max_nms;
+    if (L.m_cap < 1) L.m_cap = 1;
+    L.m_pad = (int)pow2_ceil_host((uint32_t)(L.m_cap < 2 ? 2 : L.m_cap));
+    size_t o = 0;
+    L.off_counts = o; o = align_up(o + sizeof(int) * bs, 256);
+    L.off_range = o; o = align_up(o + sizeof(img_range) * bs, 256);
+    L.off_keep = o; o = align_up(o + (size_t)bs * L.m_cap, 256);
+    L.off_keys = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.cap_pad, 256);
+    L.off_keys2 = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.m_pad, 256);
+    L.off_det = o; o = align_up(o + sizeof(float) * 6 * (size_t)bs * L.m_cap, 256);
+    L.off_spill = o; o = align_up(o + sizeof(float4) * (size_t)bs * L.m_cap, 256);
+    L.total = o;
+    return L;
+}
+
+__global__ void k_nms_init(int* counts, img_range* range, int bs)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bs) {
+        counts[i] = 0;
+        range[i].lo = 0x7fffffff;       // above every float_order()
+        range[i].hi = (int)0x80000000;
+        range[i].bad = 0;
+        range[i].pad = 0;
+    }
+}
+
+float round_down_to_float(double t)
+{
+    float f = (float)t;
+    if ((double)f > t) f = nextafterf(f, -INFINITY);
+    return f;
+}
+
+}  // namespace
+
+extern "C" size_t dh_nms_workspace(int bs, int cap, int max_nms)
+{
+    if (bs <= 0 || cap <= 0 || max_nms <= 0) return 0;
+    return make_layout(bs, cap, max_nms).total;
+}
+
+extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres,
+                              int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
+                              int max_nms, double max_wh, int cap, float* out, int* out_count, int* cand_count,
+                              void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (bs < 0 || bs > 65535 || A < 1 || nc < 1 || max_det < 1 || max_nms < 1 || cap < 1) return DH_ERR_ARG;
+    if ((long long)A * nc >= (1ll << 32)) return DH_ERR_ARG;
+    if (bs == 0) return DH_OK;
+    if (!pred || !out || !out_count || !cand_count || !workspace) return DH_ERR_ARG;
+    const nms_layout L = make_layout(bs, cap, max_nms);
+    if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    int* counts = (int*)(ws + L.off_counts);
+    img_range* range = (img_range*)(ws + L.off_range);
+    unsigned char* keep = (unsigned char*)(ws + L.off_keep);
+    u64* keys = (u64*)(ws + L.off_keys);
+    u64* keys2 = (u64*)(ws + L.off_keys2);
+    float* det = (float*)(ws + L.off_det);
+    float4* spill = (float4*)(ws + L.off_spill);
+    hipStream_t st = (hipStream_t)stream;
+    const float conf = (float)conf_thres;
+    const float thr = round_down_to_float(iou_thres);
+
+    hipLaunchKernelGGL(k_nms_init, dim3((bs + 255) / 256), dim3(256), 0, st, counts, range, bs);
+    if (hipMemsetAsync(keep, 0, (size_t)bs * L.m_cap, st) != hipSuccess) return DH_ERR_LAUNCH;
+    int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks
+    const int gx_cap = 8192 / bs > 1 ? 8192 / bs : 1;
+    if (gx > gx_cap) gx = gx_cap;
+    if (multi_label)
+        hipLaunchKernelGGL(k_nms_prefilter<true>, dim3(gx, bs), dim3(256), 0, st, pred, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
+    else
+        hipLaunchKernelGGL(k_nms_prefilter<false>, dim3(gx, bs), dim3(256), 0, st, pred, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
+    hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys, counts, cap, L.cap_pad);
+    hipLaunchKernelGGL(k_nms_gather, dim3((L.m_cap + 255) / 256, bs), dim3(256), 0, st, pred, A, dh_make_fastdiv((uint32_t)nc),
+                       keys, L.cap_pad, counts, cap, max_nms, det, keys2, L.m_pad, L.m_cap, range);
+    if (!agnostic) {
+        // keys2 holds m = min(n, max_nms) entries per image; k_sort_keys clamps to `limit`
+        hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys2, counts, L.m_cap, L.m_pad);
+        hipLaunchKernelGGL(k_nms_greedy<4>, dim3(nc, bs), dim3(256), 0, st, det, keys2, L.m_pad, L.m_cap, counts, cap,
+                           max_nms, range, 0, (float)max_wh, thr, max_det, keep, spill);
+    } else {
+        hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, bs), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, counts, cap,
+                           max_nms, range, 1, (float)max_wh, thr, max_det, keep, spill);
+    }
+    hipLaunchKernelGGL(k_nms_collect, dim3(bs), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, cap, max_nms,
+                       max_det, out, (long long*)nullptr, out_count);
+    if (hipMemcpyAsync(cand_count, counts, sizeof(int) * bs, hipMemcpyDeviceToDevice, st) != hipSuccess) return DH_ERR_LAUNCH;
+    return dh_launch_status();
+}
+
+extern "C" size_t dh_nms_plain_workspace(int64_t n)
+{
+    if (n <= 0 || n >= (1ll << 31)) return 0;
+    return make_layout(1, (int)n, (int)n).total;
+}
+
+extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
+                            int* keep_count, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (n < 0 || n >= (1ll << 31) || !keep_count) return DH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (!boxes || !scores || !keep_index || !workspace) return DH_ERR_ARG;
+    const int ni = (int)n;
+    const nms_layout L = make_layout(1, ni, ni);
+    if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    int* counts = (int*)(ws + L.off_counts);
+    img_range* range = (img_range*)(ws + L.off_range);
+    unsigned char* keep = (unsigned char*)(ws + L.off_keep);
+    u64* keys = (u64*)(ws + L.off_keys);
+    u64* keys2 = (u64*)(ws + L.off_keys2);
+    float* det = (float*)(ws + L.off_det);
+    float4* spill = (float4*)(ws + L.off_spill);
+    if (hipMemsetAsync(keep, 0, (size_t)L.m_cap, st) != hipSuccess) return DH_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_nms_plain_keys, dim3((ni + 255) / 256), dim3(256), 0, st, scores, ni, keys, counts);
+    hipLaunchKernelGGL(k_sort_keys, dim3(1), dim3(SORT_THREADS), 0, st, keys, counts, ni, L.cap_pad);
+    hipLaunchKernelGGL(k_nms_plain_gather, dim3((ni + 255) / 256), dim3(256), 0, st, boxes, keys, ni, det);
+    hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, 1), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, counts, ni, ni, range,
+                       1, 0.0f, round_down_to_float(iou_thres), ni, keep, spill);
+    hipLaunchKernelGGL(k_nms_collect, dim3(1), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, ni, ni, ni,
+                       (float*)nullptr, (long long*)keep_index, keep_count);
+    return dh_launch_status();
+}

@@ -1,0 +1,148 @@
+"""Drop-ins for object_detection/yolov5/utils/general.py:543-560,619-738
+(xyxy2xywh, xywh2xyxy, scale_coords, clip_coords, non_max_suppression)."""
+import numpy as np
+import torch
+
+from . import _lib as L
+
+MAX_WH = 7680      # general.py:663
+MAX_NMS = 30000    # general.py:664
+
+
+def _convert(x, mode):
+    if isinstance(x, torch.Tensor):
+        src = L.dev_f32(x, "x")
+        if src.dim() != 2 or src.shape[1] < 4:
+            raise RuntimeError(f"expected (n, >=4) boxes, got {tuple(x.shape)}")
+        if src.stride(1) != 1:
+            src = src.contiguous()
+        y = src.clone(memory_format=torch.contiguous_format)
+        with torch.cuda.device(src.device):
+            L.check(L.lib().dh_box_convert(L.ptr(src), src.stride(0), L.ptr(y), y.stride(0), src.shape[0], mode,
+                                           L.stream()), "dh_box_convert")
+        return y if x.dtype == torch.float32 else y.to(x.dtype)
+    # numpy inputs stay on the host: that interface has no device to run on
+    y = np.copy(x)
+    if mode == 0:
+        y[:, 0], y[:, 1] = x[:, 0] - x[:, 2] / 2, x[:, 1] - x[:, 3] / 2
+        y[:, 2], y[:, 3] = x[:, 0] + x[:, 2] / 2, x[:, 1] + x[:, 3] / 2
+    else:
+        y[:, 0], y[:, 1] = (x[:, 0] + x[:, 2]) / 2, (x[:, 1] + x[:, 3]) / 2
+        y[:, 2], y[:, 3] = x[:, 2] - x[:, 0], x[:, 3] - x[:, 1]
+    return y
+
+
+def xywh2xyxy(x):
+    """(n,>=4) [x,y,w,h,...] -> [x1,y1,x2,y2,...] copy (general.py:553-560)."""
+    return _convert(x, 0)
+
+
+def xyxy2xywh(x):
+    """(n,>=4) [x1,y1,x2,y2,...] -> [x,y,w,h,...] copy (general.py:543-550)."""
+    return _convert(x, 1)
+
+
+def _scale_clip(boxes, do_scale, pad, gain, shape):
+    if boxes.dtype != torch.float32 or not boxes.is_cuda:
+        raise RuntimeError("scale_coords/clip_coords modify fp32 ROCm tensors in place; got "
+                           f"{boxes.dtype} on {boxes.device}")
+    if boxes.dim() != 2 or boxes.shape[1] < 4 or boxes.stride(1) != 1:
+        raise RuntimeError(f"expected a row-major (n, >=4) view, got shape {tuple(boxes.shape)} stride {boxes.stride()}")
+    with torch.cuda.device(boxes.device):
+        L.check(L.lib().dh_scale_clip_coords(L.ptr(boxes), boxes.stride(0), boxes.shape[0], int(do_scale), float(pad[0]),
+                                             float(pad[1]), float(gain), float(shape[1]), float(shape[0]), L.stream()),
+                "dh_scale_clip_coords")
+
+
+def clip_coords(boxes, shape):
+    """Clip xyxy boxes to (height, width) in place (general.py:635-644)."""
+    if isinstance(boxes, torch.Tensor):
+        _scale_clip(boxes, False, (0.0, 0.0), 1.0, shape)
+    else:
+        boxes[:, [0, 2]] = boxes[:, [0, 2]].clip(0, shape[1])
+        boxes[:, [1, 3]] = boxes[:, [1, 3]].clip(0, shape[0])
+
+
+def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
+    """Map xyxy coords from the letterboxed img1_shape back to img0_shape in place (general.py:619-632)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (img1_shape[1] - img0_shape[1] * gain) / 2, (img1_shape[0] - img0_shape[0] * gain) / 2
+    else:
+        gain = ratio_pad[0][0]
+        pad = ratio_pad[1]
+    _scale_clip(coords, True, pad, gain, img0_shape)
+    return coords
+
+
+def _with_apriori_labels(pred, labels, nc):
+    """general.py:678-684: label rows [cls,x,y,w,h] join an image's candidates with obj = cls score = 1.
+
+    They are appended as extra prediction rows (objectness 0 rows pad shorter images and can never be
+    candidates), which keeps them behind every real anchor in candidate order, as in the reference.
+    """
+    extra = max((len(l) for l in labels), default=0)
+    if extra == 0:
+        return pred
+    bs = pred.shape[0]
+    pad = torch.zeros((bs, extra, nc + 5), dtype=torch.float32, device=pred.device)
+    for i, l in enumerate(labels):
+        if len(l):
+            l = l.to(pred.device).float()
+            pad[i, :len(l), :4] = l[:, 1:5]
+            pad[i, :len(l), 4] = 1.0
+            pad[i, torch.arange(len(l), device=pred.device), l[:, 0].long() + 5] = 1.0
+    return torch.cat((pred, pad), 1)
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=(), max_det=300):
+    """Batched NMS on (bs, A, 5+nc) predictions -> list of (k,6) [xyxy, conf, cls] per image (general.py:647-738).
+
+    The whole batch is processed by one sequence of kernel launches and a single device-to-host copy
+    of the per-image counts; the returned tensors are views of one (bs, max_det, 6) buffer.
+    The reference's 10 s wall-clock bail-out (general.py:734-736) is not reproduced.
+    """
+    assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
+    assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
+    pred = L.dev_f32(prediction, "prediction").contiguous()
+    if pred.dim() != 3 or pred.shape[2] < 6:
+        raise RuntimeError(f"prediction must be (bs, A, 5+nc) with nc >= 1, got {tuple(prediction.shape)}")
+    bs, _, no = pred.shape
+    nc = no - 5
+    multi_label = bool(multi_label) and nc > 1                                      # general.py:667
+    if labels and len(labels):
+        pred = _with_apriori_labels(pred, labels, nc)
+    A = pred.shape[1]
+    dev = pred.device
+    if bs == 0 or A == 0:
+        return [torch.zeros((0, 6), device=dev)] * bs
+    max_det = int(max_det)
+    if max_det < 1:
+        return [torch.zeros((0, 6), device=dev)] * bs
+    keep_mask = None
+    if classes is not None:
+        flags = torch.zeros(nc, dtype=torch.uint8)
+        idx = [int(c) for c in classes if float(c) == int(c) and 0 <= int(c) < nc]
+        if idx:
+            flags[idx] = 1
+        keep_mask = flags.to(dev)
+    lib = L.lib()
+    out = torch.empty((bs, max_det, 6), dtype=torch.float32, device=dev)
+    counts = torch.empty((2, bs), dtype=torch.int32, device=dev)                    # [kept rows, candidates found]
+    cap = A
+    while True:
+        ws_bytes = lib.dh_nms_workspace(bs, cap, MAX_NMS)
+        ws = L.workspace(ws_bytes, dev)
+        with torch.cuda.device(dev):
+            L.check(lib.dh_nms_batched(L.ptr(pred), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
+                                       int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap,
+                                       L.ptr(out), L.ptr(counts[0]), L.ptr(counts[1]), L.ptr(ws), ws_bytes, L.stream()),
+                    "dh_nms_batched")
+        host = counts.cpu()
+        found = int(host[1].max())
+        if found <= cap:
+            break
+        cap = found            # multi-label produced more candidates than rows: rerun with room for all of them
+    empty = torch.zeros((0, 6), device=dev)
+    return [out[i, :k] if k else empty for i, k in enumerate(host[0].tolist())]

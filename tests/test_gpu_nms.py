@@ -1,0 +1,160 @@
+"""GPU parity: batched non_max_suppression, plain nms and the box-format helpers.
+
+Kept rows, their order and every float in them must be bit-identical to the oracle / the reference
+fixtures: the whole stage consists of IEEE add/sub/mul/div and comparisons only.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import nms as onms
+from tests._synth import make_big_pred, synth_pred
+from tests.test_oracle_golden import NMS_VARIANTS, nms_labels, unpack
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def same_lists(got, want):
+    assert [int(d.shape[0]) for d in got] == [int(w.shape[0]) for w in want]
+    for d, w in zip(got, want):
+        w = w.numpy() if isinstance(w, torch.Tensor) else w
+        np.testing.assert_array_equal(d.cpu().numpy(), w)
+
+
+@pytest.mark.parametrize("tag", list(NMS_VARIANTS))
+def test_non_max_suppression_golden(golden, tag):
+    from object_detection_amd.general import non_max_suppression
+    g = golden("nms")
+    kw = dict(NMS_VARIANTS[tag])
+    if tag == "labels":
+        kw["labels"] = [l.cuda() for l in nms_labels(g)]
+    pred = T(g["pred"]).cuda()
+    before = pred.clone()
+    got = non_max_suppression(pred, **kw)
+    same_lists(got, unpack(g, tag))
+    assert torch.equal(pred, before)          # the input is not modified (the reference works on a copy)
+
+
+def test_nms_single_class_ties_and_big(golden):
+    from object_detection_amd.general import non_max_suppression
+    g = golden("nms")
+    same_lists(non_max_suppression(T(g["nc1_pred"]).cuda(), conf_thres=0.1, multi_label=True), unpack(g, "nc1"))
+    for key, kw in (("tie", {}), ("tie_multi", {"multi_label": True})):
+        same_lists(non_max_suppression(T(g["tie_pred"]).cuda(), conf_thres=0.05, iou_thres=0.5, **kw), unpack(g, key))
+    big = make_big_pred()
+    got = non_max_suppression(T(big).cuda(), conf_thres=0.01, iou_thres=0.5, multi_label=True, max_det=300)
+    same_lists(got, unpack(g, "big"))
+
+
+def test_nms_asserts_and_empty():
+    from object_detection_amd.general import non_max_suppression
+    pred = torch.zeros((2, 10, 9), device="cuda")
+    with pytest.raises(AssertionError):
+        non_max_suppression(pred, conf_thres=1.5)
+    with pytest.raises(AssertionError):
+        non_max_suppression(pred, iou_thres=-0.1)
+    out = non_max_suppression(pred)
+    assert len(out) == 2 and all(o.shape == (0, 6) for o in out)
+
+
+@pytest.mark.parametrize("kw", [dict(conf_thres=0.25, iou_thres=0.45), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+                                dict(conf_thres=0.05, iou_thres=0.5, agnostic=True, max_det=1000),
+                                dict(conf_thres=0.02, iou_thres=0.3, multi_label=True, classes=[1, 3, 5, 79], max_det=50)])
+def test_nms_bs8_25200_vs_oracle(kw):
+    """Decoded-prediction shaped input of the 640 px head: bs 8 x 25200 anchors x 80 classes."""
+    from object_detection_amd.general import non_max_suppression
+    rs = np.random.RandomState(101)
+    pred = synth_pred(rs, 8, 25200, 80, n_obj=12, k_per_obj=40)      # score ties allowed: oracle and HIP pin the same stable order
+    want = onms.non_max_suppression(T(pred).clone(), **kw)
+    got = non_max_suppression(T(pred).cuda(), **kw)
+    same_lists(got, want)
+    assert sum(w.shape[0] for w in want) > 50
+
+
+def test_nms_dense_stress_vs_oracle():
+    """> 30000 candidates per image: top-30000 cut, long class segments, kept lists beyond the LDS part."""
+    from object_detection_amd.general import non_max_suppression
+    rs = np.random.RandomState(77)
+    bs, A, nc = 2, 60000, 4
+    pred = np.zeros((bs, A, 5 + nc), dtype=np.float32)
+    pred[..., 0:2] = rs.uniform(0, 640, (bs, A, 2))
+    pred[..., 2:4] = np.exp(rs.uniform(np.log(4), np.log(64), (bs, A, 2)))
+    pred[..., 4] = rs.uniform(0.3, 1, (bs, A))
+    logits = rs.normal(0, 3, (bs, A, nc))
+    pred[..., 5:] = np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)
+    for kw in (dict(conf_thres=0.25, iou_thres=0.45, max_det=300), dict(conf_thres=0.25, iou_thres=0.45, max_det=30000),
+               dict(conf_thres=0.25, iou_thres=0.6, agnostic=True, max_det=2000)):
+        want = onms.non_max_suppression(T(pred).clone(), **kw)
+        got = non_max_suppression(T(pred).cuda(), **kw)
+        same_lists(got, want)
+
+
+def test_nms_huge_boxes_cross_class_overlap():
+    """Boxes wider than the 7680 px class offset overlap across classes in the reference; so must we."""
+    from object_detection_amd.general import non_max_suppression
+    rs = np.random.RandomState(8)
+    pred = synth_pred(rs, 2, 500, 6, n_obj=4, k_per_obj=10)
+    pred[0, :40, 0:2] = rs.uniform(0, 9000, (40, 2))
+    pred[0, :40, 2:4] = rs.uniform(6000, 20000, (40, 2))
+    pred[0, :40, 4] = rs.uniform(0.5, 1, 40)
+    pred[0, :40, 5:] = rs.uniform(0.3, 1, (40, 6))
+    for kw in (dict(conf_thres=0.2), dict(conf_thres=0.1, multi_label=True, iou_thres=0.3)):
+        same_lists(non_max_suppression(T(pred).cuda(), **kw), onms.non_max_suppression(T(pred).clone(), **kw))
+
+
+def test_plain_nms_known_answers_and_random():
+    from object_detection_amd.ops import nms
+    f = np.float32
+    sq = lambda x, y, s: [x, y, x + s, y + s]
+
+    def run(b, s, thr):
+        return nms(T(f(b)).cuda(), T(f(s)).cuda(), thr).cpu().tolist()
+    assert run([sq(0, 0, 10), sq(20, 20, 10), sq(40, 40, 10)], [.2, .9, .5], 0.5) == [1, 2, 0]
+    assert run([sq(0, 0, 10)] * 3, [.5, .5, .5], 0.5) == [0]
+    assert run([[0, 0, 2, 1], [0, 0, 1, 1]], [.9, .8], 0.5) == [0, 1]            # IoU == thr is kept (strict >)
+    assert run([[0, 0, 2, 1], [0, 0, 1, 1]], [.9, .8], 0.4999) == [0]
+    assert run([[0, 0, 5, 1], [0, 0, 3, 1]], [.9, .8], 0.6) == [0]               # float32(0.6) > 0.6 in double
+    assert run([[1, 1, 1, 1], [1, 1, 1, 1]], [.9, .8], 0.1) == [0, 1]            # 0/0 -> NaN -> kept
+    assert run([[0, 0, 10, 10], [4, 0, 14, 10], [8, 0, 18, 10]], [.9, .8, .7], 0.4) == [0, 2]
+    k = nms(torch.zeros((0, 4), device="cuda"), torch.zeros((0,), device="cuda"), 0.5)
+    assert k.dtype == torch.int64 and k.numel() == 0
+    rs = np.random.RandomState(5)
+    for n in (1, 63, 64, 65, 200, 5000, 20000):
+        b = rs.uniform(0, 300, (n, 2)).astype(f)
+        b = np.concatenate([b, b + rs.uniform(5, 60, (n, 2)).astype(f)], 1)
+        s = rs.uniform(-1, 1, n).astype(f)
+        s[::7] = s[n // 2]                                                       # score ties, negative scores
+        for thr in (0.0, 0.3, 0.6, 1.0):
+            want = onms.nms(T(b), T(s), thr)
+            got = nms(T(b).cuda(), T(s).cuda(), thr)
+            assert got.cpu().tolist() == want.tolist(), (n, thr)
+
+
+def test_box_utils(golden):
+    from object_detection_amd import general as G
+    g = golden("box_utils")
+    eq = lambda a, b: np.testing.assert_array_equal(a.cpu().numpy() if isinstance(a, torch.Tensor) else a, b)
+    eq(G.xywh2xyxy(T(g["xywh"]).cuda()), g["xywh2xyxy"])
+    eq(G.xyxy2xywh(T(g["xywh2xyxy"]).cuda()), g["xyxy2xywh"])
+    eq(G.xywh2xyxy(g["xywh"].copy()), g["xywh2xyxy_np"])
+    det = T(g["scale_in"]).cuda()
+    out = G.scale_coords((640, 640), det, (720, 1280, 3))
+    assert out.data_ptr() == det.data_ptr()                       # in place, returns its argument
+    eq(det, g["scale_a"])
+    eq(G.scale_coords((384, 640), T(g["scale_in"]).cuda(), (1080, 1920)), g["scale_b"])
+    eq(G.scale_coords((640, 640), T(g["scale_in"]).cuda(), (500, 375), ratio_pad=((0.8, 0.8), (10.0, 20.0))), g["scale_c"])
+    c = T(g["scale_in"]).cuda()
+    G.clip_coords(c, (300, 400))
+    eq(c, g["clip_t"])
+    cn = g["scale_in"].copy()
+    G.clip_coords(cn, (300, 400))
+    eq(cn, g["clip_np"])
+    # a (n,6) detection view as the callers pass it (val.py: scale_coords(im.shape, predn[:, :4], ...))
+    d6 = T(g["scale_in"]).cuda()
+    G.scale_coords((640, 640), d6[:, :4], (720, 1280, 3))
+    eq(d6, g["scale_a"])
