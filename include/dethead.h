@@ -98,6 +98,42 @@ int dh_box_convert(const float* in, int64_t in_row_stride, float* out, int64_t o
 int dh_scale_clip_coords(float* boxes, int64_t row_stride, int64_t n, int do_scale, double pad_x, double pad_y,
                          double gain, double max_x, double max_y, void* stream);
 
+/* ComputeLoss.build_targets (object_detection/yolov5/utils/loss.py:169-222) for all nl levels.
+ * targets (nt,6) [image,class,x,y,w,h] and anchors (nl,na,2, grid units) on the device; ny/nx host
+ * arrays.  Per level l, rows [0,counts[l]) of:  idx[l][0..3][cap] = image, anchor, gj, gi planes
+ * (int64), tbox[l][cap][4], anch[l][cap][2], tcls[l][cap] (int64), in the reference's row order.
+ * cap >= 5*na*nt rows are reserved per level. */
+size_t dh_build_targets_workspace(int nl, int na, int64_t nt);
+int dh_build_targets(const float* targets, int64_t nt, const float* anchors, int nl, int na, const int* ny, const int* nx,
+                     double anchor_t, int64_t cap, int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* Hyper-parameters of ComputeLoss (loss.py:93-115): gains box/obj/cls, BCE pos_weights, focal gamma
+ * (0 = plain BCE), smoothed class targets cp/cn (loss.py:13-15,103), iou ratio gr (loss.py:113) and the
+ * per-level objectness balance (loss.py:111). */
+typedef struct dh_yolo_hyp {
+    float box, obj, cls, cls_pw, obj_pw, fl_gamma, cp, cn, gr;
+    float balance[DH_MAX_LEVELS];
+} dh_yolo_hyp;
+
+/* ComputeLoss.__call__ (loss.py:117-167) given the assignment produced by dh_build_targets.
+ * p / grad_p: host arrays of nl device pointers to (bs,na,ny,nx,5+nc) maps.
+ * out (device, 5+nl floats): [0] loss, [1..3] lbox, lobj, lcls after gains, [4..4+nl) mean objectness
+ * BCE per level (what autobalance reads, loss.py:158), [4+nl] rows ignored because their image/anchor
+ * index was outside the maps.  The forward leaves in `workspace` what the backward needs (per-row IoU and
+ * the cell-owner map), so the same workspace must be passed to dh_yolo_loss_bwd unmodified.
+ * The backward writes every element of every grad_p[l] (no pre-zeroing needed); grad_loss is the
+ * upstream gradient of out[0] (1 float, device). */
+size_t dh_yolo_loss_workspace(const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t cap);
+int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                     const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
+                     int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace, size_t workspace_bytes,
+                     void* stream);
+int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                     const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
+                     int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_p,
+                     const void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,14 @@ SIGNATURES = {
     "dh_box_convert": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "dh_scale_clip_coords": (c_int, [c_void_p, c_i64, c_i64, c_int, c_double, c_double, c_double, c_double, c_double,
                                      c_void_p]),
+    "dh_build_targets_workspace": (c_size_t, [c_int, c_int, c_i64]),
+    "dh_build_targets": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_double, c_i64, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_yolo_loss_workspace": (c_size_t, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64]),
+    "dh_yolo_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_yolo_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None
@@ -86,6 +94,12 @@ def dev_f32(t, name="tensor"):
 def workspace(nbytes, device):
     """256-byte aligned scratch from torch's caching allocator."""
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=device)
+
+
+class YoloHyp(ctypes.Structure):
+    """Mirror of dh_yolo_hyp in include/dethead.h."""
+    _fields_ = [(n, c_float) for n in ("box", "obj", "cls", "cls_pw", "obj_pw", "fl_gamma", "cp", "cn", "gr")] + [
+        ("balance", c_float * 5)]
 
 
 def int_array(values):

@@ -1,0 +1,169 @@
+// YOLOv5 target assignment (anchor matching + neighbour-cell expansion) for all levels in one launch.
+//
+// Reference: object_detection/yolov5/utils/loss.py:169-222 (ComputeLoss.build_targets).
+//   for each level: t = targets * [1,1,nx,ny,nx,ny]; keep (anchor a, target t) when
+//   max(r, 1/r) over w,h < anchor_t with r = gwh / anchors[a]; expand each kept row to the cell
+//   itself plus up to four neighbours chosen by the fractional position of gxy; cell indices are
+//   trunc(gxy - offset) clamped to the grid; tbox = (gxy - cell, gwh).
+// Output order is the reference's: offset-major {centre,+x,+y,-x,-y}, then anchor-major, then target
+// order -- two row-major boolean compactions (loss.py:194,202).  It is reproduced with
+// order-preserving ballot/prefix-scan compaction (no atomics), one workgroup per level.
+// The clamp of loss.py:217 works in place on views of the cell tensor, so tbox uses clamped cells.
+#include "dh_common.h"
+#include "../../include/dethead.h"
+
+namespace {
+
+#define BT_THREADS 1024
+
+struct bt_params {
+    int ny[DH_MAX_LEVELS];
+    int nx[DH_MAX_LEVELS];
+    int nl, na;
+    int nt;
+    float anchor_t;
+    long cap;   // rows reserved per level = 5*na*nt
+};
+
+__device__ __forceinline__ int block_rank(bool flag, int& total, int* s_w)
+{
+    const unsigned long long m = __ballot(flag);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < BT_THREADS / 64; ++w) {
+        const int c = s_w[w];
+        if (w < wave) before += c;
+        all += c;
+    }
+    __syncthreads();
+    total = all;
+    return before + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// torch.remainder(x, 1) for fp32 (fmod, then shift a negative result up by the divisor)
+__device__ __forceinline__ float remainder_one(float x)
+{
+    float m = fmodf(x, 1.0f);
+    if (m != 0.0f && m < 0.0f) m += 1.0f;
+    return m;
+}
+
+__global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __restrict__ targets,
+                                                              const float* __restrict__ anchors, const bt_params P,
+                                                              int* __restrict__ list_ws, long long* __restrict__ idx,
+                                                              float* __restrict__ tbox, float* __restrict__ anch,
+                                                              long long* __restrict__ tcls, int* __restrict__ counts)
+{
+    __shared__ int s_w[BT_THREADS / 64];
+    const int l = blockIdx.x;
+    const int nx = P.nx[l], ny = P.ny[l];
+    const float fnx = (float)nx, fny = (float)ny;
+    const int total_q = P.na * P.nt;
+    int* __restrict__ list = list_ws + (size_t)l * total_q;
+    const float* __restrict__ anc = anchors + (size_t)l * P.na * 2;
+
+    // stage 1: (anchor, target) pairs that pass the ratio test, in anchor-major order (loss.py:191-194)
+    int n1 = 0;
+    for (int q0 = 0; q0 < total_q; q0 += BT_THREADS) {
+        const int q = q0 + threadIdx.x;
+        bool ok = false;
+        if (q < total_q) {
+            const int a = q / P.nt, t = q - a * P.nt;
+            const float gw = targets[(size_t)t * 6 + 4] * fnx, gh = targets[(size_t)t * 6 + 5] * fny;
+            const float rw = __fdiv_rn(gw, anc[2 * a]), rh = __fdiv_rn(gh, anc[2 * a + 1]);
+            const float worst = fmaxf(fmaxf(rw, __fdiv_rn(1.0f, rw)), fmaxf(rh, __fdiv_rn(1.0f, rh)));
+            ok = worst < P.anchor_t;
+        }
+        int tot;
+        const int rank = block_rank(ok, tot, s_w);
+        if (ok) list[n1 + rank] = q;
+        n1 += tot;
+    }
+    __syncthreads();   // list[] written by this workgroup is read back below
+
+    // stage 2: one pass per neighbour offset keeps the offset-major order (loss.py:197-203)
+    long long* __restrict__ ob = idx + (size_t)l * 4 * P.cap;
+    long long* __restrict__ oa = ob + P.cap;
+    long long* __restrict__ oj = oa + P.cap;
+    long long* __restrict__ oi = oj + P.cap;
+    float* __restrict__ obox = tbox + (size_t)l * P.cap * 4;
+    float* __restrict__ oanch = anch + (size_t)l * P.cap * 2;
+    long long* __restrict__ ocls = tcls + (size_t)l * P.cap;
+    int n2 = 0;
+    for (int off = 0; off < 5; ++off) {
+        for (int k0 = 0; k0 < n1; k0 += BT_THREADS) {
+            const int k = k0 + threadIdx.x;
+            bool take = false;
+            int a = 0, t = 0;
+            float gx = 0.f, gy = 0.f;
+            if (k < n1) {
+                const int q = list[k];
+                a = q / P.nt; t = q - a * P.nt;
+                gx = targets[(size_t)t * 6 + 2] * fnx;
+                gy = targets[(size_t)t * 6 + 3] * fny;
+                if (off == 0) take = true;
+                else if (off == 1) take = (remainder_one(gx) < 0.5f) && (gx > 1.0f);
+                else if (off == 2) take = (remainder_one(gy) < 0.5f) && (gy > 1.0f);
+                else if (off == 3) { const float ix = fnx - gx; take = (remainder_one(ix) < 0.5f) && (ix > 1.0f); }
+                else { const float iy = fny - gy; take = (remainder_one(iy) < 0.5f) && (iy > 1.0f); }
+            }
+            int tot;
+            const int rank = block_rank(take, tot, s_w);
+            if (take) {
+                const size_t pos = (size_t)n2 + rank;
+                const float ox = off == 1 ? 0.5f : (off == 3 ? -0.5f : 0.0f);
+                const float oy = off == 2 ? 0.5f : (off == 4 ? -0.5f : 0.0f);
+                long long gi = (long long)(gx - ox), gj = (long long)(gy - oy);           // .long(): truncation
+                gi = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);                            // loss.py:217
+                gj = gj < 0 ? 0 : (gj > ny - 1 ? ny - 1 : gj);
+                const float* __restrict__ tr = targets + (size_t)t * 6;
+                ob[pos] = (long long)tr[0];
+                oa[pos] = a;
+                oj[pos] = gj;
+                oi[pos] = gi;
+                obox[4 * pos + 0] = gx - (float)gi;
+                obox[4 * pos + 1] = gy - (float)gj;
+                obox[4 * pos + 2] = tr[4] * fnx;
+                obox[4 * pos + 3] = tr[5] * fny;
+                oanch[2 * pos + 0] = anc[2 * a];
+                oanch[2 * pos + 1] = anc[2 * a + 1];
+                ocls[pos] = (long long)tr[1];
+            }
+            n2 += tot;
+        }
+    }
+    if (threadIdx.x == 0) counts[l] = n2;
+}
+
+}  // namespace
+
+extern "C" size_t dh_build_targets_workspace(int nl, int na, int64_t nt)
+{
+    if (nl <= 0 || na <= 0 || nt <= 0) return 256;
+    return (size_t)nl * na * nt * sizeof(int) + 256;
+}
+
+extern "C" int dh_build_targets(const float* targets, int64_t nt, const float* anchors, int nl, int na, const int* ny,
+                                const int* nx, double anchor_t, int64_t cap, int64_t* idx, float* tbox, float* anch,
+                                int64_t* tcls, int* counts, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || nt < 0 || !ny || !nx || !counts || !anchors) return DH_ERR_ARG;
+    if ((long long)na * nt >= (1ll << 30)) return DH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (nt == 0) return hipMemsetAsync(counts, 0, sizeof(int) * nl, st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (!targets || !idx || !tbox || !anch || !tcls || !workspace || cap < 5ll * na * nt) return DH_ERR_ARG;
+    if (workspace_bytes < dh_build_targets_workspace(nl, na, nt)) return DH_ERR_WORKSPACE;
+    bt_params P;
+    for (int l = 0; l < nl; ++l) {
+        if (ny[l] < 1 || nx[l] < 1) return DH_ERR_ARG;
+        P.ny[l] = ny[l];
+        P.nx[l] = nx[l];
+    }
+    P.nl = nl; P.na = na; P.nt = (int)nt; P.anchor_t = (float)anchor_t; P.cap = (long)cap;
+    hipLaunchKernelGGL(k_build_targets, dim3(nl), dim3(BT_THREADS), 0, st, targets, anchors, P, (int*)workspace,
+                       (long long*)idx, tbox, anch, (long long*)tcls, counts);
+    return dh_launch_status();
+}

@@ -1,0 +1,439 @@
+// YOLOv5 ComputeLoss forward and backward over all levels.
+//
+// Reference: object_detection/yolov5/utils/loss.py:117-167 (ComputeLoss.__call__), :35-62 (FocalLoss),
+//            torch.nn.BCEWithLogitsLoss(pos_weight) for the element formula.
+//   per level i:  ps = pi[b,a,gj,gi];  pxy = 2s-0.5, pwh = (2s)^2*anchor;  iou = CIoU(pbox, tbox)
+//                 lbox += mean(1-iou);  tobj[b,a,gj,gi] = (1-gr) + gr*clamp(iou,0)  (duplicates: last row wins)
+//                 lcls += mean BCE(ps[:,5:], onehot(cp,cn));  lobj += mean BCE(pi[...,4], tobj) * balance[i]
+//   loss = (lbox*box + lobj*obj + lcls*cls) * bs
+//
+// Forward = 3 launches: positives (one wave per assigned row), dense objectness (reads the strided
+// obj logit of every anchor + a 4-byte owner word), finalisation.  The dense tobj tensor is never
+// built: a per-cell owner map (last assigned row, by atomicMax of the row id) stands in for it.
+// Backward = 2 launches: one streaming pass writes the whole dense gradient (zeros + obj term,
+// 16-byte stores), then the positive rows add their box / class terms.
+#include "dh_iou.h"
+#include "../../include/dethead.h"
+
+namespace {
+
+struct yl_level {
+    const float* p;      // (bs, na, ny, nx, no)
+    float* g;            // gradient, same shape (backward only)
+    int ny, nx;
+    long cells;          // bs*na*ny*nx
+    long cell_first;     // offset of this level in the owner map
+    unsigned blocks;     // dense-pass blocks of this level
+    float balance;
+};
+
+struct yl_params {
+    yl_level lvl[DH_MAX_LEVELS];
+    int nl, bs, na, nc, no;
+    long cap;
+    float box, obj, cls, cls_pw, obj_pw, gamma, cp, cn, gr;
+};
+
+#define FOCAL_ALPHA 0.25f   // default alpha of FocalLoss (loss.py:37); ComputeLoss never overrides it
+
+// BCEWithLogits(x, t, pos_weight pw), optionally wrapped by FocalLoss(gamma)
+__device__ __forceinline__ float bce_value(float x, float t, float pw, float gamma)
+{
+    const float lw = (pw - 1.0f) * t + 1.0f;
+    float l = (1.0f - t) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.0f));
+    if (gamma > 0.0f) {
+        const float p = 1.0f / (1.0f + expf(-x));
+        const float pt = t * p + (1.0f - t) * (1.0f - p);
+        const float af = t * FOCAL_ALPHA + (1.0f - t) * (1.0f - FOCAL_ALPHA);
+        l *= af * powf(1.0f - pt, gamma);
+    }
+    return l;
+}
+
+__device__ __forceinline__ float bce_grad(float x, float t, float pw, float gamma)
+{
+    const float lw = (pw - 1.0f) * t + 1.0f;
+    const float s = 1.0f / (1.0f + expf(-x));
+    const float d = lw * s - pw * t;          // = (1-t) - lw*(1-s) without the cancellation at small s
+    if (!(gamma > 0.0f)) return d;
+    const float l = (1.0f - t) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.0f));
+    const float pt = t * s + (1.0f - t) * (1.0f - s);
+    const float af = t * FOCAL_ALPHA + (1.0f - t) * (1.0f - FOCAL_ALPHA);
+    const float om = 1.0f - pt;
+    const float mf = powf(om, gamma);
+    const float dmf = -gamma * powf(om, gamma - 1.0f) * ((2.0f * t - 1.0f) * s * (1.0f - s));
+    return af * (d * mf + l * dmf);
+}
+
+struct pos_row {
+    long cell;     // index of (b,a,gj,gi) inside the level
+    int cls;
+    float tb[4], an[2];
+    bool ok;
+};
+
+__device__ __forceinline__ pos_row load_pos(const yl_params& P, const yl_level& L, int l, long r,
+                                            const long long* __restrict__ idx, const float* __restrict__ tbox,
+                                            const float* __restrict__ anch, const long long* __restrict__ tcls)
+{
+    pos_row R;
+    const long long* base = idx + (size_t)l * 4 * P.cap;
+    const long long b = base[r], a = base[P.cap + r], gj = base[2 * P.cap + r], gi = base[3 * P.cap + r];
+    R.ok = b >= 0 && b < P.bs && a >= 0 && a < P.na && gj >= 0 && gj < L.ny && gi >= 0 && gi < L.nx;
+    R.cell = ((b * P.na + a) * L.ny + gj) * L.nx + gi;
+    const float4 tb = *reinterpret_cast<const float4*>(tbox + ((size_t)l * P.cap + r) * 4);
+    R.tb[0] = tb.x; R.tb[1] = tb.y; R.tb[2] = tb.z; R.tb[3] = tb.w;
+    const float2 an = *reinterpret_cast<const float2*>(anch + ((size_t)l * P.cap + r) * 2);
+    R.an[0] = an.x; R.an[1] = an.y;
+    R.cls = (int)tcls[(size_t)l * P.cap + r];
+    return R;
+}
+
+// ------------------------------------------------------------------------------------ forward: positives
+__global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const long long* __restrict__ idx,
+                                                    const float* __restrict__ tbox, const float* __restrict__ anch,
+                                                    const long long* __restrict__ tcls, const int* __restrict__ counts,
+                                                    int* __restrict__ owner, float* __restrict__ iou_ws,
+                                                    float* __restrict__ cls_ws, int* __restrict__ invalid)
+{
+    const int l = blockIdx.y;
+    const yl_level& L = P.lvl[l];
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= counts[l]) return;
+    const pos_row R = load_pos(P, L, l, r, idx, tbox, anch, tcls);
+    float* __restrict__ iou_out = iou_ws + (size_t)l * P.cap;
+    float* __restrict__ cls_out = cls_ws + (size_t)l * P.cap;
+    if (!R.ok) {      // image / anchor index outside the tensors: contributes nothing, counted for the caller
+        if (lane == 0) { iou_out[r] = 1.0f; cls_out[r] = 0.0f; atomicAdd(invalid, 1); }
+        return;
+    }
+    const float* __restrict__ ps = L.p + (size_t)R.cell * P.no;
+    const float x0 = ps[0], x1 = ps[1], x2 = ps[2], x3 = ps[3];
+    const float px = dh_sigmoid(x0) * 2.0f - 0.5f, py = dh_sigmoid(x1) * 2.0f - 0.5f;          // loss.py:132
+    const float tw = dh_sigmoid(x2) * 2.0f, th = dh_sigmoid(x3) * 2.0f;
+    const float pw = (tw * tw) * R.an[0], ph = (th * th) * R.an[1];                             // loss.py:133
+    const float iou = dh_iou_value<DH_CIOU>(dh_from_xywh(px, py, pw, ph), dh_from_xywh(R.tb[0], R.tb[1], R.tb[2], R.tb[3]),
+                                            1e-7f, (float)(1.0 + 1e-7));
+    float csum = 0.0f;
+    if (P.nc > 1) {                                                                             // loss.py:146-149
+        for (int c = lane; c < P.nc; c += 64)
+            csum += bce_value(ps[5 + c], c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma);
+        csum = dh_wave_sum(csum);
+    }
+    if (lane == 0) {
+        iou_out[r] = iou;
+        cls_out[r] = csum;
+        atomicMax(owner + L.cell_first + R.cell, (int)r);      // last assigned row owns the cell (loss.py:143)
+    }
+}
+
+// ------------------------------------------------------------------------------------ forward: dense objectness
+__device__ __forceinline__ int level_of_block(const yl_params& P, unsigned& blk)
+{
+    int l = 0;
+#pragma unroll
+    for (int k = 0; k < DH_MAX_LEVELS - 1; ++k)
+        if (l == k && k + 1 < P.nl && blk >= P.lvl[k].blocks) { blk -= P.lvl[k].blocks; l = k + 1; }
+    return l;
+}
+
+__device__ __forceinline__ float tobj_of(const yl_params& P, int own, const float* __restrict__ iou_l)
+{
+    if (own < 0) return 0.0f;
+    return (1.0f - P.gr) + P.gr * fmaxf(iou_l[own], 0.0f);                                       // loss.py:139,143
+}
+
+#define OBJ_CELLS_PER_BLOCK 1024
+
+__global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int* __restrict__ owner,
+                                                    const float* __restrict__ iou_ws, double* __restrict__ partial)
+{
+    unsigned blk = blockIdx.x;
+    const int l = level_of_block(P, blk);
+    const yl_level& L = P.lvl[l];
+    const float* __restrict__ iou_l = iou_ws + (size_t)l * P.cap;
+    const int* __restrict__ own_l = owner + L.cell_first;
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < OBJ_CELLS_PER_BLOCK / 256; ++u) {
+        const long cell = (long)blk * OBJ_CELLS_PER_BLOCK + u * 256 + threadIdx.x;
+        if (cell < L.cells) {
+            const float x = L.p[(size_t)cell * P.no + 4];
+            acc += (double)bce_value(x, tobj_of(P, own_l[cell], iou_l), P.obj_pw, P.gamma);       // loss.py:155
+        }
+    }
+    __shared__ double red[4];
+    acc = dh_wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out: [0] loss, [1..3] lbox,lobj,lcls (after gains), [4..4+nl) mean objectness BCE per level, [4+nl] ignored rows
+__global__ void __launch_bounds__(256) k_yl_final(const yl_params P, const int* __restrict__ counts,
+                                                  const float* __restrict__ iou_ws, const float* __restrict__ cls_ws,
+                                                  const double* __restrict__ partial, const int* __restrict__ invalid,
+                                                  float* __restrict__ out)
+{
+    __shared__ double red[3][4];
+    __shared__ float s_box[DH_MAX_LEVELS], s_cls[DH_MAX_LEVELS], s_obj[DH_MAX_LEVELS];
+    unsigned first_block = 0;
+    for (int l = 0; l < P.nl; ++l) {
+        const int n = counts[l];
+        double sb = 0.0, sc = 0.0, so = 0.0;
+        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+            sb += (double)(1.0f - iou_ws[(size_t)l * P.cap + r]);
+            sc += (double)cls_ws[(size_t)l * P.cap + r];
+        }
+        for (unsigned k = threadIdx.x; k < P.lvl[l].blocks; k += blockDim.x) so += partial[first_block + k];
+        first_block += P.lvl[l].blocks;
+        sb = dh_wave_sum_d(sb); sc = dh_wave_sum_d(sc); so = dh_wave_sum_d(so);
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = sc; red[2][threadIdx.x >> 6] = so; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double tb = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+            const double tc = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            const double to = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+            s_box[l] = n > 0 ? (float)(tb / n) : 0.0f;
+            s_cls[l] = (n > 0 && P.nc > 1) ? (float)(tc / ((double)n * P.nc)) : 0.0f;
+            s_obj[l] = (float)(to / (double)P.lvl[l].cells);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
+        for (int l = 0; l < P.nl; ++l) {
+            lbox += s_box[l];
+            lcls += s_cls[l];
+            lobj += s_obj[l] * P.lvl[l].balance;                                                 // loss.py:156
+            out[4 + l] = s_obj[l];
+        }
+        lbox *= P.box; lobj *= P.obj; lcls *= P.cls;                                             // loss.py:162-164
+        out[0] = (lbox + lobj + lcls) * (float)P.bs;
+        out[1] = lbox; out[2] = lobj; out[3] = lcls;
+        out[4 + P.nl] = (float)invalid[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward: dense pass
+// Writes every element of the gradient once: zero everywhere except the objectness channel.
+#define GRAD_VEC_PER_BLOCK 1024
+
+template <int VEC>
+__global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const int* __restrict__ owner,
+                                                    const float* __restrict__ iou_ws, const float* __restrict__ g_loss,
+                                                    const dh_fastdiv nod)
+{
+    unsigned blk = blockIdx.x;
+    const int l = level_of_block(P, blk);
+    const yl_level& L = P.lvl[l];
+    const float* __restrict__ iou_l = iou_ws + (size_t)l * P.cap;
+    const int* __restrict__ own_l = owner + L.cell_first;
+    const float scale = g_loss[0] * (float)P.bs * P.obj * L.balance / (float)L.cells;
+    const size_t total = (size_t)L.cells * P.no;
+    const size_t nvec = total / VEC;
+#pragma unroll
+    for (int u = 0; u < GRAD_VEC_PER_BLOCK / 256; ++u) {
+        const size_t v = (size_t)blk * GRAD_VEC_PER_BLOCK + u * 256 + threadIdx.x;
+        if (v >= nvec) continue;
+        const size_t e = v * VEC;
+        // position of the objectness element (channel 4) relative to this vector
+        const uint32_t cell = dh_div((uint32_t)e, nod);          // total < 2^32 is checked on the host
+        const uint32_t c0 = (uint32_t)e - cell * nod.d;
+        float o[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o[k] = 0.0f;
+        // channel 4 of `cell` sits at offset 4 - c0; of the next cell at 4 - c0 + no
+        int k4 = 4 - (int)c0;
+        uint32_t hit = cell;
+        if (k4 < 0) { k4 += (int)nod.d; hit = cell + 1; }
+        if (k4 < VEC && hit < (uint32_t)L.cells) {
+            const float x = L.p[(size_t)hit * P.no + 4];
+            const float g = scale * bce_grad(x, tobj_of(P, own_l[hit], iou_l), P.obj_pw, P.gamma);
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) if (k == k4) o[k] = g;
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(L.g + e) = make_float4(o[0], o[1], o[2], o[3]);
+        else L.g[e] = o[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward: positives
+__global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const long long* __restrict__ idx,
+                                                    const float* __restrict__ tbox, const float* __restrict__ anch,
+                                                    const long long* __restrict__ tcls, const int* __restrict__ counts,
+                                                    const float* __restrict__ g_loss)
+{
+    const int l = blockIdx.y;
+    const yl_level& L = P.lvl[l];
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = counts[l];
+    if (r >= n) return;
+    const pos_row R = load_pos(P, L, l, r, idx, tbox, anch, tcls);
+    if (!R.ok) return;
+    const float* __restrict__ ps = L.p + (size_t)R.cell * P.no;
+    float* __restrict__ gs = L.g + (size_t)R.cell * P.no;
+    const float up = g_loss[0] * (float)P.bs;
+    if (lane < 4) {
+        const float x0 = ps[0], x1 = ps[1], x2 = ps[2], x3 = ps[3];
+        const float s0 = dh_sigmoid(x0), s1 = dh_sigmoid(x1), s2 = dh_sigmoid(x2), s3 = dh_sigmoid(x3);
+        const float tw = s2 * 2.0f, th = s3 * 2.0f;
+        const dh_corners a = dh_from_xywh(s0 * 2.0f - 0.5f, s1 * 2.0f - 0.5f, (tw * tw) * R.an[0], (th * th) * R.an[1]);
+        dh_corners gc;
+        // d lbox / d iou = -box/n  (lbox += mean(1 - iou))
+        dh_iou_value_grad<DH_CIOU>(a, dh_from_xywh(R.tb[0], R.tb[1], R.tb[2], R.tb[3]), 1e-7f, (float)(1.0 + 1e-7),
+                                   -up * P.box / (float)n, gc);
+        float gx, gy, gw, gh;
+        dh_grad_to_xywh(gc, gx, gy, gw, gh);
+        float g;
+        if (lane == 0) g = gx * 2.0f * s0 * (1.0f - s0);
+        else if (lane == 1) g = gy * 2.0f * s1 * (1.0f - s1);
+        else if (lane == 2) g = gw * (2.0f * tw * R.an[0]) * (2.0f * s2 * (1.0f - s2));
+        else g = gh * (2.0f * th * R.an[1]) * (2.0f * s3 * (1.0f - s3));
+        atomicAdd(gs + lane, g);            // duplicates of one cell accumulate, as index_put(accumulate) does
+    }
+    if (P.nc > 1) {
+        const float sc = up * P.cls / ((float)n * (float)P.nc);
+        for (int c = lane; c < P.nc; c += 64)
+            atomicAdd(gs + 5 + c, sc * bce_grad(ps[5 + c], c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma));
+    }
+}
+
+struct yl_ws {
+    size_t off_owner, off_iou, off_cls, off_partial, off_invalid, total;
+    long cells_total;
+    unsigned obj_blocks;
+};
+
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
+
+bool make_params(const float* const* p, float* const* g, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                 long cap, const dh_yolo_hyp* hyp, bool grad_blocks, yl_params& P, yl_ws& W)
+{
+    if (nl < 1 || nl > DH_MAX_LEVELS || bs < 1 || na < 1 || nc < 1 || cap < 0 || !ny || !nx) return false;
+    P.nl = nl; P.bs = bs; P.na = na; P.nc = nc; P.no = nc + 5; P.cap = cap;
+    if (hyp) {
+        P.box = hyp->box; P.obj = hyp->obj; P.cls = hyp->cls; P.cls_pw = hyp->cls_pw; P.obj_pw = hyp->obj_pw;
+        P.gamma = hyp->fl_gamma; P.cp = hyp->cp; P.cn = hyp->cn; P.gr = hyp->gr;
+    }
+    long first = 0;
+    unsigned blocks = 0;
+    for (int l = 0; l < nl; ++l) {
+        if (ny[l] < 1 || nx[l] < 1) return false;
+        yl_level& L = P.lvl[l];
+        L.p = p ? p[l] : nullptr;
+        L.g = g ? g[l] : nullptr;
+        L.ny = ny[l]; L.nx = nx[l];
+        L.cells = (long)bs * na * ny[l] * nx[l];
+        if ((unsigned long long)L.cells * P.no >= (1ull << 32)) return false;
+        L.cell_first = first;
+        first += L.cells;
+        if (grad_blocks) {
+            const size_t total = (size_t)L.cells * P.no;
+            const size_t nvec = (total % 4 == 0) ? total / 4 : total;
+            L.blocks = (unsigned)((nvec + GRAD_VEC_PER_BLOCK - 1) / GRAD_VEC_PER_BLOCK);
+        } else {
+            L.blocks = (unsigned)((L.cells + OBJ_CELLS_PER_BLOCK - 1) / OBJ_CELLS_PER_BLOCK);
+        }
+        blocks += L.blocks;
+        L.balance = hyp ? hyp->balance[l] : 0.0f;
+    }
+    W.cells_total = first;
+    // workspace layout is independent of grad_blocks: obj_blocks is always the forward count
+    unsigned fwd_blocks = 0;
+    for (int l = 0; l < nl; ++l) fwd_blocks += (unsigned)((P.lvl[l].cells + OBJ_CELLS_PER_BLOCK - 1) / OBJ_CELLS_PER_BLOCK);
+    W.obj_blocks = fwd_blocks;
+    size_t o = 0;
+    W.off_owner = o; o = up256(o + sizeof(int) * (size_t)first);
+    W.off_iou = o; o = up256(o + sizeof(float) * (size_t)nl * (cap > 0 ? cap : 1));
+    W.off_cls = o; o = up256(o + sizeof(float) * (size_t)nl * (cap > 0 ? cap : 1));
+    W.off_partial = o; o = up256(o + sizeof(double) * fwd_blocks);
+    W.off_invalid = o; o = up256(o + sizeof(int));
+    W.total = o;
+    (void)blocks;
+    return true;
+}
+
+unsigned sum_blocks(const yl_params& P)
+{
+    unsigned b = 0;
+    for (int l = 0; l < P.nl; ++l) b += P.lvl[l].blocks;
+    return b;
+}
+
+}  // namespace
+
+extern "C" size_t dh_yolo_loss_workspace(const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t cap)
+{
+    yl_params P;
+    yl_ws W;
+    if (!make_params(nullptr, nullptr, ny, nx, nl, bs, na, nc, (long)cap, nullptr, false, P, W)) return 0;
+    return W.total;
+}
+
+extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                                const int* counts, int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace,
+                                size_t workspace_bytes, void* stream)
+{
+    yl_params P;
+    yl_ws W;
+    if (!p || !hyp || !out || !counts || !workspace) return DH_ERR_ARG;
+    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W)) return DH_ERR_ARG;
+    for (int l = 0; l < nl; ++l) if (!p[l]) return DH_ERR_ARG;
+    if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
+    if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && !dh_aligned16(tbox))) return DH_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    int* owner = (int*)(ws + W.off_owner);
+    float* iou_ws = (float*)(ws + W.off_iou);
+    float* cls_ws = (float*)(ws + W.off_cls);
+    double* partial = (double*)(ws + W.off_partial);
+    int* invalid = (int*)(ws + W.off_invalid);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(owner, 0xFF, sizeof(int) * (size_t)W.cells_total, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (hipMemsetAsync(invalid, 0, sizeof(int), st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (cap > 0)
+        hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
+                           anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+    hipLaunchKernelGGL(k_yl_obj_fwd, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial);
+    hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(256), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
+    return dh_launch_status();
+}
+
+extern "C" int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                                const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
+                                float* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream)
+{
+    yl_params P;
+    yl_ws W;
+    if (!p || !grad_p || !hyp || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
+    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, P, W)) return DH_ERR_ARG;
+    bool vec4 = true;
+    for (int l = 0; l < nl; ++l) {
+        if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
+        vec4 = vec4 && ((size_t)P.lvl[l].cells * P.no) % 4 == 0 && dh_aligned16(grad_p[l]);
+    }
+    if (!vec4) {   // scalar stores: one element per "vector"
+        for (int l = 0; l < nl; ++l) {
+            const size_t total = (size_t)P.lvl[l].cells * P.no;
+            P.lvl[l].blocks = (unsigned)((total + GRAD_VEC_PER_BLOCK - 1) / GRAD_VEC_PER_BLOCK);
+        }
+    }
+    if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
+    if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
+    const char* ws = (const char*)workspace;
+    const int* owner = (const int*)(ws + W.off_owner);
+    const float* iou_ws = (const float*)(ws + W.off_iou);
+    hipStream_t st = (hipStream_t)stream;
+    const dh_fastdiv nod = dh_make_fastdiv((uint32_t)P.no);
+    if (vec4) hipLaunchKernelGGL(k_yl_obj_bwd<4>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, grad_loss, nod);
+    else hipLaunchKernelGGL(k_yl_obj_bwd<1>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, grad_loss, nod);
+    if (cap > 0)
+        hipLaunchKernelGGL(k_yl_pos_bwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
+                           anch, (const long long*)tcls, counts, grad_loss);
+    return dh_launch_status();
+}

@@ -1,0 +1,153 @@
+"""Drop-in for ComputeLoss (object_detection/yolov5/utils/loss.py:91-222)."""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+def smooth_BCE(eps=0.1):
+    """Positive / negative label-smoothing BCE targets (loss.py:13-15)."""
+    return 1.0 - 0.5 * eps, 0.5 * eps
+
+
+def is_parallel(model):
+    """object_detection/yolov5/utils/torch_utils.py:145-147."""
+    return type(model) in (nn.parallel.DataParallel, nn.parallel.DistributedDataParallel)
+
+
+class _Assignment:
+    """Padded device buffers produced by dh_build_targets plus the per-level row counts (device)."""
+
+    def __init__(self, shapes, nt, na, nl, device):
+        self.ny = [int(s[0]) for s in shapes]
+        self.nx = [int(s[1]) for s in shapes]
+        self.nl, self.na, self.nt = nl, na, int(nt)
+        self.cap = 5 * na * self.nt
+        rows = max(self.cap, 1)
+        self.idx = torch.empty((nl, 4, rows), dtype=torch.int64, device=device)
+        self.tbox = torch.empty((nl, rows, 4), dtype=torch.float32, device=device)
+        self.anch = torch.empty((nl, rows, 2), dtype=torch.float32, device=device)
+        self.tcls = torch.empty((nl, rows), dtype=torch.int64, device=device)
+        self.counts = torch.empty(nl, dtype=torch.int32, device=device)
+
+
+def _assign(level_shapes, targets, anchors, anchor_t):
+    """Run the assignment kernel; nothing is copied back to the host."""
+    tg = L.dev_f32(targets, "targets").contiguous()
+    if tg.dim() != 2 or tg.shape[1] != 6:
+        raise RuntimeError(f"targets must be (nt,6) [image,class,x,y,w,h], got {tuple(targets.shape)}")
+    anc = L.dev_f32(anchors, "anchors").contiguous()
+    nl, na = int(anc.shape[0]), int(anc.shape[1])
+    A = _Assignment(level_shapes, tg.shape[0], na, nl, tg.device)
+    lib = L.lib()
+    ws_bytes = lib.dh_build_targets_workspace(nl, na, A.nt)
+    ws = L.workspace(ws_bytes, tg.device)
+    with torch.cuda.device(tg.device):
+        L.check(lib.dh_build_targets(L.ptr(tg), A.nt, L.ptr(anc), nl, na, L.int_array(A.ny), L.int_array(A.nx),
+                                     float(anchor_t), A.cap, L.ptr(A.idx), L.ptr(A.tbox), L.ptr(A.anch), L.ptr(A.tcls),
+                                     L.ptr(A.counts), L.ptr(ws), ws_bytes, L.stream()), "dh_build_targets")
+    return A
+
+
+class _YoloLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, assign, hyp, nc, *p):
+        maps = [L.dev_f32(x, f"p[{i}]").contiguous() for i, x in enumerate(p)]
+        nl = len(maps)
+        bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
+        for x, ny, nx in zip(maps, assign.ny, assign.nx):
+            if tuple(x.shape) != (bs, na, ny, nx, nc + 5):
+                raise RuntimeError(f"ComputeLoss: level shape {tuple(x.shape)} does not match (bs,na,ny,nx,5+nc)")
+        dev = maps[0].device
+        lib = L.lib()
+        ny, nx = L.int_array(assign.ny), L.int_array(assign.nx)
+        ws_bytes = lib.dh_yolo_loss_workspace(ny, nx, nl, bs, na, nc, assign.cap)
+        if ws_bytes == 0:
+            raise RuntimeError("ComputeLoss: unsupported problem size (a level exceeds 2^32 elements)")
+        ws = L.workspace(ws_bytes, dev)
+        out = torch.empty(5 + nl, dtype=torch.float32, device=dev)
+        ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
+        with torch.cuda.device(dev):
+            L.check(lib.dh_yolo_loss_fwd(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
+                                         L.ptr(assign.anch), L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap,
+                                         ctypes.byref(hyp), L.ptr(out), L.ptr(ws), ws_bytes, L.stream()),
+                    "dh_yolo_loss_fwd")
+        ctx.save_for_backward(*maps)
+        ctx.state = (assign, hyp, nc, ws, ws_bytes, [x.dtype for x in p])
+        loss = out[0:1].clone()
+        ctx.mark_non_differentiable(out)
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_out):
+        maps = ctx.saved_tensors
+        assign, hyp, nc, ws, ws_bytes, dtypes = ctx.state
+        nl = len(maps)
+        bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
+        grads = [torch.empty_like(x) for x in maps]
+        g = g_loss.reshape(1).float().contiguous()
+        ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
+        gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
+        with torch.cuda.device(maps[0].device):
+            L.check(L.lib().dh_yolo_loss_bwd(ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc,
+                                             L.ptr(assign.idx), L.ptr(assign.tbox), L.ptr(assign.anch),
+                                             L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap, ctypes.byref(hyp),
+                                             L.ptr(g), gptrs, L.ptr(ws), ws_bytes, L.stream()), "dh_yolo_loss_bwd")
+        return (None, None, None) + tuple(gr if dt == torch.float32 else gr.to(dt) for gr, dt in zip(grads, dtypes))
+
+
+class ComputeLoss:
+    """Same constructor, attributes and call contract as loss.py:91-167.
+
+    __call__(p, targets) -> (loss[1], loss_items[3] detached); build_targets(p, targets) ->
+    (tcls, tbox, indices, anch).  __call__ keeps the assignment on the device (no host copy, no
+    data-dependent shapes); build_targets, whose return type has data-dependent shapes, copies the
+    nl row counts to the host once.
+    """
+
+    def __init__(self, model, autobalance=False):
+        self.sort_obj_iou = False
+        h = model.hyp
+        self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
+        det = model.module.model[-1] if is_parallel(model) else model.model[-1]
+        self.balance = {3: [4.0, 1.0, 0.4]}.get(det.nl, [4.0, 1.0, 0.25, 0.06, 0.02])
+        self.ssi = list(det.stride).index(16) if autobalance else 0
+        self.gr, self.hyp, self.autobalance = 1.0, h, autobalance
+        for k in 'na', 'nc', 'nl', 'anchors':
+            setattr(self, k, getattr(det, k))
+
+    def _hyp_struct(self):
+        h = self.hyp
+        s = L.YoloHyp()
+        s.box, s.obj, s.cls = float(h['box']), float(h['obj']), float(h['cls'])
+        s.cls_pw, s.obj_pw, s.fl_gamma = float(h['cls_pw']), float(h['obj_pw']), float(h['fl_gamma'])
+        s.cp, s.cn, s.gr = float(self.cp), float(self.cn), float(self.gr)
+        for i, b in enumerate(self.balance[:self.nl]):
+            s.balance[i] = float(b)
+        return s
+
+    def __call__(self, p, targets):
+        if self.sort_obj_iou:
+            raise NotImplementedError("sort_obj_iou=True is not supported (the reference never enables it, loss.py:94)")
+        shapes = [(x.shape[2], x.shape[3]) for x in p]
+        assign = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+        loss, out = _YoloLoss.apply(assign, self._hyp_struct(), int(self.nc), *p)
+        if self.autobalance:                                                    # loss.py:157-161 (host round trip)
+            obji = out[4:4 + self.nl].tolist()
+            self.balance = [b * 0.9999 + 0.0001 / o for b, o in zip(self.balance, obji)]
+            self.balance = [x / self.balance[self.ssi] for x in self.balance]
+        return loss, out[1:4].detach()
+
+    def build_targets(self, p, targets):
+        shapes = [(x.shape[2], x.shape[3]) for x in p]
+        A = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+        counts = A.counts.tolist()
+        tcls, tbox, indices, anch = [], [], [], []
+        for l, n in enumerate(counts):
+            indices.append(tuple(A.idx[l, k, :n] for k in range(4)))            # image, anchor, gridy, gridx
+            tbox.append(A.tbox[l, :n])
+            anch.append(A.anch[l, :n])
+            tcls.append(A.tcls[l, :n])
+        return tcls, tbox, indices, anch
