@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Detection-head hot-path benchmark: decode + target assignment + CIoU loss fwd/bwd + batched NMS.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic YOLOv5s head outputs that are
+already resident in HBM: bs 64 per GPU @ 640 px, 3 levels, 80 classes (25 200 anchors / image),
+640 targets.  Weak scaling: every rank owns its own 64 images (the path shards by image); the only
+collective is one 4-float all-reduce of the loss terms and positive count per step.
+Rank 0 prints ONE JSON line; `value` = images/s over all ranks.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STRIDES = (8, 16, 32)
+ANCHORS_PX = ((10, 13, 16, 30, 33, 23), (30, 61, 62, 45, 59, 119), (116, 90, 156, 198, 373, 326))
+HYP = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (≈6.3 TB/s is what a plain copy kernel reaches)
+
+
+class _Det:
+    def __init__(self, anchors, nc):
+        self.anchors, self.nc = anchors, nc
+        self.nl, self.na = anchors.shape[0], anchors.shape[1]
+        self.stride = torch.tensor([float(s) for s in STRIDES])
+
+
+class _Model(torch.nn.Module):
+    def __init__(self, anchors, nc):
+        super().__init__()
+        self.model = [_Det(anchors, nc)]
+        self.hyp = dict(HYP)
+
+
+def grid_anchors(device):
+    a = torch.tensor(ANCHORS_PX, dtype=torch.float32).view(3, 3, 2)
+    return (a / torch.tensor(STRIDES, dtype=torch.float32).view(3, 1, 1)).to(device)
+
+
+def synth_batch(bs, img, nc, nt, seed, device):
+    """Raw head maps with the bias statistics of Detect._initialize_biases
+    (object_detection/yolov5/models/yolo.py:196-204) plus targets; a few anchors per target get
+    confident objectness / class logits so that NMS has real clusters to resolve."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    t = torch.zeros(nt, 6)
+    t[:, 0] = torch.sort(torch.randint(0, bs, (nt,), generator=gen).float())[0]
+    t[:, 1] = torch.randint(0, nc, (nt,), generator=gen).float()
+    t[:, 2:4] = torch.rand(nt, 2, generator=gen)
+    t[:, 4:6] = torch.exp(torch.rand(nt, 2, generator=gen) * (math.log(0.6) - math.log(0.01)) + math.log(0.01))
+    dgen = torch.Generator(device=device).manual_seed(seed)
+    levels = []
+    for s in STRIDES:
+        n = img // s
+        x = torch.randn((bs, 3, n, n, nc + 5), generator=dgen, device=device)
+        x[..., 4] += math.log(8 / (640 / s) ** 2)
+        x[..., 5:] += math.log(0.6 / (nc - 0.999999))
+        levels.append(x)
+    return levels, t.to(device)
+
+
+def plant_objects(levels, targets, crit):
+    """Raise obj / class logits on the cells the assignment selects, like a partly trained head."""
+    tcls, _, indices, _ = crit.build_targets(levels, targets)
+    for l, x in enumerate(levels):
+        b, a, gj, gi = indices[l]
+        if b.numel():
+            x[b, a, gj, gi, 4] = 1.5 + torch.randn(b.numel(), device=x.device)
+            x[b, a, gj, gi, 5 + tcls[l]] = 2.0 + torch.randn(b.numel(), device=x.device)
+            x[b, a, gj, gi, 0:4] *= 0.3
+    return sum(int(i[0].numel()) for i in indices)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (restatement of the reference's PyTorch path) on a bounded sample: bs 8 of the same workload."""
+    from oracle import nms as onms
+    from oracle import yolo as oy
+    bs, img, nc, nt = 8, 640, 80, 80
+    torch.manual_seed(0)
+    levels, targets = synth_batch(bs, img, nc, nt, 4242, "cpu")
+    anchors = oy.grid_anchors()
+    crit = oy.YoloLossOracle(anchors, dict(HYP), nc=nc)
+    # plant objects with the oracle's own assignment so the NMS sees the same kind of clusters
+    for l, t in enumerate(crit.targets_for(levels, targets)):
+        b, a, gj, gi = (torch.from_numpy(t[k]) for k in ("b", "a", "gj", "gi"))
+        if b.numel():
+            levels[l][b, a, gj, gi, 4] = 1.5 + torch.randn(b.numel())
+            levels[l][b, a, gj, gi, 5 + torch.from_numpy(t["tcls"])] = 2.0 + torch.randn(b.numel())
+            levels[l][b, a, gj, gi, 0:4] *= 0.3
+
+    def step():
+        z = oy.detect_decode([x.detach() for x in levels], anchors, [float(s) for s in STRIDES])
+        p = [x.detach().requires_grad_(True) for x in levels]
+        loss, _ = crit(p, targets)
+        torch.autograd.grad(loss, p)
+        onms.non_max_suppression(z, 0.25, 0.45, max_det=300)
+
+    step()
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 3 or (time.perf_counter() - t0 < seconds_budget and reps < 50):
+        step()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(bs / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"bs {bs} @ {img}px, {nt} targets, {reps} reps of decode+assign+loss fwd/bwd+NMS on the CPU oracle "
+                      f"(PyTorch-CPU restatement + C greedy NMS), {dt * 1e3:.1f} ms/step"}
+
+
+def load_pmc_traffic():
+    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return {}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from object_detection_amd.dist import all_reduce_loss_stats
+    from object_detection_amd.general import non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    from object_detection_amd.yolo_loss import ComputeLoss
+
+    bs, img, nc, nt = args.batch, 640, 80, 10 * args.batch
+    anchors = grid_anchors(device)
+    crit = ComputeLoss(_Model(anchors, nc))
+    levels, targets = synth_batch(bs, img, nc, nt, 1000 + rank, device)
+    n_planted = plant_objects(levels, targets, crit)
+    strides = torch.tensor([float(s) for s in STRIDES])
+    A = sum(3 * (img // s) ** 2 for s in STRIDES)
+    p = [x.requires_grad_(True) for x in levels]
+
+    stages = ("decode", "assign+loss_fwd", "loss_bwd", "nms", "allreduce")
+    ev = {s: [] for s in stages}
+
+    def step(record):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if record else None
+        if record: marks[0].record()
+        with torch.no_grad():
+            z = detect_decode(levels, anchors, strides)
+        if record: marks[1].record()
+        loss, items = crit(p, targets)
+        if record: marks[2].record()
+        grads = torch.autograd.grad(loss, p)
+        if record: marks[3].record()
+        dets = non_max_suppression(z, 0.25, 0.45, max_det=300)
+        if record: marks[4].record()
+        stats = all_reduce_loss_stats(items, crit.last_positive_counts)
+        if record:
+            marks[5].record()
+            return marks, dets, loss, grads, stats
+        return None, dets, loss, grads, stats
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync_all()
+    t0 = time.perf_counter()
+    all_marks = []
+    for _ in range(args.steps):
+        marks, dets, loss, grads, stats = step(True)
+        all_marks.append(marks)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    for marks in all_marks:
+        for i, s in enumerate(stages):
+            ev[s].append(marks[i].elapsed_time(marks[i + 1]))
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = bs * world * args.steps / elapsed
+    stage_ms = {s: float(np.mean(v)) for s, v in ev.items()}
+
+    # roofline of the dominant streaming kernel: the decode launch, 340 B read + 340 B written per anchor
+    decode_bytes = 680.0 * A * bs
+    decode_s = stage_ms["decode"] * 1e-3
+    achieved = decode_bytes / decode_s / 1e9
+    pmc = load_pmc_traffic()
+    roofline = {"kernel": "k_yolo_decode", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc.get("k_yolo_decode_bytes_per_launch"),
+                "algorithmic_bytes_per_launch": decode_bytes, "avg_launch_ms": round(stage_ms["decode"], 4)}
+    bwd_bytes = (340.0 + 4.0 + 4.0) * A * bs        # dense gradient write + obj logit + owner word per anchor
+    extra_kernels = {"loss_bwd_dense": {"algorithmic_GBps": round(bwd_bytes / (stage_ms["loss_bwd"] * 1e-3) / 1e9, 1),
+                                        "frac_of_peak": round(bwd_bytes / (stage_ms["loss_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec decode+assign+IoU-loss+NMS, bs=64 @640px; HBM GB/s vs peak",
+            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"YOLOv5s head, bs {bs}/GPU @ {img}px, 3 levels, nc {nc}, {A} anchors/img, {nt} targets; "
+                                   "decode + build_targets + CIoU/obj/cls loss fwd+bwd + NMS(conf 0.25, iou 0.45, max_det 300)",
+                       "global_batch": bs * world, "parallelism": f"image-sharded x{world}",
+                       "planted_positive_rows": n_planted, "detections_last_step": int(sum(d.shape[0] for d in dets))},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "roofline": roofline, "other_kernels": extra_kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

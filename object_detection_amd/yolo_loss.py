@@ -109,6 +109,7 @@ class ComputeLoss:
 
     def __init__(self, model, autobalance=False):
         self.sort_obj_iou = False
+        self.last_positive_counts = None
         h = model.hyp
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
         det = model.module.model[-1] if is_parallel(model) else model.model[-1]
@@ -133,6 +134,7 @@ class ComputeLoss:
             raise NotImplementedError("sort_obj_iou=True is not supported (the reference never enables it, loss.py:94)")
         shapes = [(x.shape[2], x.shape[3]) for x in p]
         assign = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+        self.last_positive_counts = assign.counts            # (nl,) int32 on the device: rows assigned per level
         loss, out = _YoloLoss.apply(assign, self._hyp_struct(), int(self.nc), *p)
         if self.autobalance:                                                    # loss.py:157-161 (host round trip)
             obji = out[4:4 + self.nl].tolist()
