@@ -75,7 +75,7 @@ int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx,
  * class_keep: nc bytes on the device (1 = keep class) or NULL (general.py:705-706).
  * max_nms = 30000 and max_wh = 7680 in the reference (general.py:663-664).  All of out,
  * out_count, cand_count, workspace are device memory; workspace must be 256-byte aligned. */
-size_t dh_nms_workspace(int bs, int cap, int max_nms);
+size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms);
 int dh_nms_batched(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres, int multi_label,
                    int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
                    float* out, int* out_count, int* cand_count, void* workspace, size_t workspace_bytes, void* stream);

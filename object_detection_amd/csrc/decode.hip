@@ -29,27 +29,25 @@ struct decode_params {
     uint32_t per_image;   // elements of one image's output span = A*no
 };
 
-__device__ __forceinline__ float decode_one(const decode_params& P, const decode_level& L, uint32_t e, float x)
+// box channels (c < 4) of row `row`: xy = (2s - 0.5 + grid) * stride, wh = (2s)^2 * anchor_px
+__device__ __forceinline__ float decode_box(const decode_level& L, uint32_t row, uint32_t c, float s)
 {
-    const float s = dh_sigmoid(x);
-    const uint32_t row = dh_div(e, P.no);
-    const uint32_t c = e - row * P.no.d;
-    if (c >= 4) return s;
     const uint32_t a = dh_div(row, L.plane);
     const uint32_t cell = row - a * L.plane.d;
-    if (c < 2) {
-        const uint32_t gy = dh_div(cell, L.nx);
-        const uint32_t gx = cell - gy * L.nx.d;
-        const float g = (float)(c == 0 ? gx : gy);
-        return (s * 2.0f - 0.5f + g) * L.stride;
-    }
+    const uint32_t gy = dh_div(cell, L.nx);
+    const uint32_t gx = cell - gy * L.nx.d;
+    const float g = (float)((c & 1u) ? gy : gx);
+    const float xy = (s * 2.0f - 0.5f + g) * L.stride;
     const float t = s * 2.0f;
-    return (t * t) * L.anchor_px[2 * a + (c - 2)];
+    const float wh = (t * t) * L.anchor_px[2 * a + (c & 1u)];
+    return c < 2 ? xy : wh;
 }
 
 // One block owns DH_DEC_UNROLL*256 consecutive vectors of ONE level of ONE image, so the level
 // record is wave-uniform (scalar registers).  VEC = 4 needs every level span to be a multiple of
-// 4 floats and 16-byte aligned; VEC = 1 is the general fallback.
+// 4 floats and 16-byte aligned; VEC = 1 is the general fallback.  Every element gets its sigmoid
+// unconditionally; the 4-of-`no` box channels are patched afterwards, once per vector, so the hot
+// path has a single division by `no` and one (rarely taken) branch per 16 bytes.
 #define DH_DEC_UNROLL 4
 
 template <int VEC>
@@ -64,34 +62,46 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
     }
     const decode_level& L = P.lvl[l];
     const uint32_t nvec = L.elems / VEC;
+    const uint32_t no = P.no.d;
     const float* __restrict__ src = L.src + (size_t)b * L.elems;
     float* __restrict__ dst = out + (size_t)b * P.per_image + L.first;
     const uint32_t v0 = blk * (256 * DH_DEC_UNROLL) + threadIdx.x;
     if (VEC == 4) {
-        float4 x[DH_DEC_UNROLL];
+        dh_f4 x[DH_DEC_UNROLL];
 #pragma unroll
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
             const uint32_t v = v0 + u * 256;
-            if (v < nvec) x[u] = *reinterpret_cast<const float4*>(src + (size_t)v * 4);
+            if (v < nvec) x[u] = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(src + (size_t)v * 4));
         }
 #pragma unroll
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
             const uint32_t v = v0 + u * 256;
-            if (v < nvec) {
-                const uint32_t e = v * 4;
-                float4 y;
-                y.x = decode_one(P, L, e + 0, x[u].x);
-                y.y = decode_one(P, L, e + 1, x[u].y);
-                y.z = decode_one(P, L, e + 2, x[u].z);
-                y.w = decode_one(P, L, e + 3, x[u].w);
-                *reinterpret_cast<float4*>(dst + (size_t)e) = y;
+            if (v >= nvec) continue;
+            const uint32_t e = v * 4;
+            float y[4] = {dh_sigmoid(x[u].x), dh_sigmoid(x[u].y), dh_sigmoid(x[u].z), dh_sigmoid(x[u].w)};
+            const uint32_t row = dh_div(e, P.no);
+            const uint32_t c0 = e - row * no;
+            if (c0 < 4 || c0 + 3 >= no) {           // the vector touches box channels of `row` or of `row + 1`
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t c = c0 + k, r = row;
+                    if (c >= no) { c -= no; r += 1; }
+                    if (c < 4) y[k] = decode_box(L, r, c, y[k]);
+                }
             }
+            const dh_f4 o = {y[0], y[1], y[2], y[3]};
+            *reinterpret_cast<dh_f4*>(dst + (size_t)e) = o;
         }
     } else {
 #pragma unroll
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
             const uint32_t v = v0 + u * 256;
-            if (v < nvec) dst[v] = decode_one(P, L, v, src[v]);
+            if (v >= nvec) continue;
+            float y = dh_sigmoid(src[v]);
+            const uint32_t row = dh_div(v, P.no);
+            const uint32_t c = v - row * no;
+            if (c < 4) y = decode_box(L, row, c, y);
+            dst[v] = y;
         }
     }
 }

@@ -11,6 +11,8 @@
 
 #define DH_WAVE 64
 
+typedef float dh_f4 __attribute__((ext_vector_type(4)));   // native 16-byte vector (usable with the nontemporal builtins)
+
 static inline int dh_launch_status() { return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH; }
 static inline bool dh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

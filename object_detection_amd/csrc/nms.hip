@@ -13,7 +13,7 @@
 //                 [~order(score) : 32 | anchor*nc + class : 32]  -> ascending key order is
 //                 "score descending, then reference candidate order", i.e. the stable refinement
 //                 of the reference's unstable sorts, independent of the emission order.
-//   2 sort        per-image bitonic sort of the keys (LDS resident up to 8192 keys, global+LDS beyond)
+//   2 sort        per-image bitonic sort of the keys (LDS resident up to 16384 keys, global+LDS beyond)
 //   3 gather      rank -> box corners / conf / class rows, second key [class : 32 | rank : 32]
 //   4 sort        per-image sort by (class, rank): each class becomes a contiguous, score-ordered segment
 //   5 greedy      one workgroup per (class, image) segment: 64 candidates at a time are tested against
@@ -31,7 +31,7 @@ namespace {
 typedef unsigned long long u64;
 
 #define SORT_THREADS 1024
-#define SORT_LDS_KEYS 8192
+#define SORT_LDS_KEYS 16384   // 128 KiB of the CU's 160 KiB LDS: one resident sorter per CU
 #define KEY_SENTINEL 0xFFFFFFFFFFFFFFFFull
 #define STAGE_KEYS 512
 #define KEPT_LDS 1024
@@ -71,7 +71,10 @@ __device__ __forceinline__ row_best wave_argmax_first(float v, int c)
     return r;
 }
 
-template <bool MULTI>
+// NCH > 0: the class scores of the rows in flight are fetched up front as NCH chunks of 64 classes
+// (nc <= 64*NCH), which keeps 4*NCH independent loads in flight per wave; NCH = 0 handles any nc
+// chunk by chunk.
+template <bool MULTI, int NCH>
 __global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__ pred, int A, int nc, float conf,
                                                        const unsigned char* __restrict__ class_keep, int cap,
                                                        u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
@@ -111,12 +114,24 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__
             int bc[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { bv[k] = -INFINITY; bc[k] = 0x7fffffff; }
-            for (int c0 = 0; c0 < nc; c0 += 64) {
-                const int c = c0 + lane;
-                float v[4];
+            float pre[4][NCH > 0 ? NCH : 1];
+            if (NCH > 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    v[k] = (c < nc) ? img[(size_t)(row0 + r[k]) * no + 5 + c] : 0.0f;
+#pragma unroll
+                    for (int h = 0; h < NCH; ++h)
+                        pre[k][h] = (h * 64 + lane < nc) ? img[(size_t)(row0 + r[k]) * no + 5 + h * 64 + lane] : 0.0f;
+            }
+            const int nch = NCH > 0 ? NCH : (nc + 63) / 64;
+#pragma unroll
+            for (int h = 0; h < nch; ++h) {
+                const int c = h * 64 + lane;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (NCH > 0) v[k] = pre[k][NCH > 0 ? h : 0];
+                    else v[k] = (c < nc) ? img[(size_t)(row0 + r[k]) * no + 5 + c] : 0.0f;
+                }
                 const bool keepc = (c < nc) && (class_keep == nullptr || class_keep[c] != 0);   // general.py:705-706
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -180,20 +195,52 @@ __device__ __forceinline__ void cmpswap(u64& a, u64& b, bool ascending)
     if ((a > b) == ascending) { const u64 t = a; a = b; b = t; }
 }
 
+// R consecutive steps (j = 2^h, 2^(h-1), ..., 2^(h-R+1)) of stage k of the bitonic network in one
+// LDS pass: a thread pulls the 2^R keys that differ only in those R index bits into registers,
+// runs the R compare-exchange steps there, and writes them back.  All 2^R keys share the stage
+// direction because bit k lies above every j bit.  This cuts LDS traffic (the limiter of an
+// LDS-resident bitonic sort) by R.
+template <int R>
+__device__ __forceinline__ void bitonic_pass(u64* s, uint32_t chunk, uint32_t gbase, uint32_t k, uint32_t h)
+{
+    const uint32_t low = h + 1 - R;                       // lowest of the R bit positions
+    const uint32_t lowmask = (1u << low) - 1u;
+    for (uint32_t t = threadIdx.x; t < (chunk >> R); t += blockDim.x) {
+        const uint32_t base = ((t & ~lowmask) << R) | (t & lowmask);
+        u64 v[1 << R];
+#pragma unroll
+        for (int q = 0; q < (1 << R); ++q) v[q] = s[base | ((uint32_t)q << low)];
+        const bool asc = ((gbase + base) & k) == 0;
+#pragma unroll
+        for (int r = R - 1; r >= 0; --r) {
+#pragma unroll
+            for (int q = 0; q < (1 << R); ++q) {
+                if (!(q & (1 << r))) {
+                    const u64 a = v[q], c = v[q | (1 << r)];
+                    const bool sw = (a > c) == asc;
+                    v[q] = sw ? c : a;
+                    v[q | (1 << r)] = sw ? a : c;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < (1 << R); ++q) s[base | ((uint32_t)q << low)] = v[q];
+    }
+    __syncthreads();
+}
+
 // all (k, j) steps of the bitonic network with j < chunk, on `chunk` keys held in LDS;
 // `gbase` is the global position of s[0] (it fixes the direction bits for k > chunk).
 __device__ void bitonic_lds(u64* s, uint32_t chunk, uint32_t gbase, uint32_t k_first, uint32_t k_last)
 {
     for (uint32_t k = k_first; k <= k_last; k <<= 1) {
-        for (uint32_t j = (k >> 1) < chunk ? (k >> 1) : (chunk >> 1); j > 0; j >>= 1) {
-            for (uint32_t t = threadIdx.x; t < chunk / 2; t += blockDim.x) {
-                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const uint32_t l = i | j;
-                const bool asc = ((gbase + i) & k) == 0;
-                u64 a = s[i], c = s[l];
-                if ((a > c) == asc) { s[i] = c; s[l] = a; }
-            }
-            __syncthreads();
+        const uint32_t jtop = (k >> 1) < chunk ? (k >> 1) : (chunk >> 1);
+        int h = 31 - __clz(jtop);                         // bit position of the first step's j
+        while (h >= 0) {
+            if (h >= 3 && chunk >= 16) { bitonic_pass<4>(s, chunk, gbase, k, (uint32_t)h); h -= 4; }
+            else if (h == 2 && chunk >= 8) { bitonic_pass<3>(s, chunk, gbase, k, 2u); h -= 3; }
+            else if (h == 1 && chunk >= 4) { bitonic_pass<2>(s, chunk, gbase, k, 1u); h -= 2; }
+            else { bitonic_pass<1>(s, chunk, gbase, k, (uint32_t)h); h -= 1; }
         }
     }
 }
@@ -205,21 +252,42 @@ __device__ __forceinline__ uint32_t pow2_ceil(uint32_t n)
     return p;
 }
 
+// first/last position of every class in a sorted [class:32 | rank:32] key array -> seg[class] = {begin, end}
+__device__ void write_segments(const u64* k, int n, int2* __restrict__ seg)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t c = (uint32_t)(k[i] >> 32);
+        if (i == 0) seg[c].x = 0;
+        else {
+            const uint32_t prev = (uint32_t)(k[i - 1] >> 32);
+            if (prev != c) { seg[c].x = i; seg[prev].y = i; }
+        }
+        if (i == n - 1) seg[c].y = n;
+    }
+}
+
 // One workgroup sorts one image's keys ascending.  n = min(counts[b], limit).
+// seg_all != nullptr: the keys are [class | rank]; also record each class's [begin, end) (zero-initialised by the caller).
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ keys_all, const int* __restrict__ counts,
-                                                            int limit, int cap_pad)
+                                                            int limit, int cap_pad, int2* __restrict__ seg_all, int nc)
 {
     __shared__ u64 s[SORT_LDS_KEYS];
     u64* __restrict__ keys = keys_all + (size_t)blockIdx.x * cap_pad;
+    int2* __restrict__ seg = seg_all ? seg_all + (size_t)blockIdx.x * nc : nullptr;
     int n = counts[blockIdx.x];
     if (n > limit) n = limit;
-    if (n <= 1) return;
+    if (n <= 0) return;
+    if (n == 1) {
+        if (seg && threadIdx.x == 0) { const uint32_t c = (uint32_t)(keys[0] >> 32); seg[c].x = 0; seg[c].y = 1; }
+        return;
+    }
     const uint32_t npad = pow2_ceil((uint32_t)n);
     if (npad <= SORT_LDS_KEYS) {
         for (uint32_t i = threadIdx.x; i < npad; i += blockDim.x) s[i] = (i < (uint32_t)n) ? keys[i] : KEY_SENTINEL;
         __syncthreads();
         bitonic_lds(s, npad, 0, 2, npad);
         for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += blockDim.x) keys[i] = s[i];
+        if (seg) write_segments(s, n, seg);
         return;
     }
     // larger than LDS: pad in global memory, sort LDS-sized chunks, then merge with global steps + LDS tails
@@ -251,6 +319,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ ke
             __syncthreads();
         }
     }
+    if (seg) write_segments(keys, n, seg);
 }
 
 // ------------------------------------------------------------------------------------------ 3 gather
@@ -301,13 +370,23 @@ __global__ void __launch_bounds__(256) k_nms_gather(const float* __restrict__ pr
         lo = fminf(lo, __shfl_xor(lo, o, 64));
         hi = fmaxf(hi, __shfl_xor(hi, o, 64));
     }
-    const u64 anybad = __ballot(bad);
-    if ((threadIdx.x & 63) == 0 && blockIdx.x * blockDim.x + (threadIdx.x & ~63) < m) {
+    __shared__ float s_lo[4], s_hi[4];
+    __shared__ int s_bad[4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_bad[wave] = __ballot(bad) != 0; }
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x * blockDim.x < m) {
+        lo = fminf(fminf(s_lo[0], s_lo[1]), fminf(s_lo[2], s_lo[3]));
+        hi = fmaxf(fmaxf(s_hi[0], s_hi[1]), fmaxf(s_hi[2], s_hi[3]));
+        // The current range is read from L2 (agent scope; a CU's L1 would keep returning the initial
+        // value) and the atomic is issued only if this block widens it, which is rare after the first few.
         if (lo <= hi) {
-            atomicMin(&range[b].lo, float_order(lo));
-            atomicMax(&range[b].hi, float_order(hi));
+            if (float_order(lo) < __hip_atomic_load(&range[b].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMin(&range[b].lo, float_order(lo));
+            if (float_order(hi) > __hip_atomic_load(&range[b].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&range[b].hi, float_order(hi));
         }
-        if (anybad) atomicOr(&range[b].bad, 1);
+        if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) atomicOr(&range[b].bad, 1);
     }
 }
 
@@ -329,16 +408,6 @@ __device__ __forceinline__ bool suppresses(const box_t a, float area_a, const bo
     return __fdiv_rn(inter, area_a + area_b - inter) > thr;
 }
 
-__device__ __forceinline__ int lower_bound_key(const u64* __restrict__ k, int n, u64 v)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (k[mid] < v) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 // WAVES waves per workgroup.  grid = (number of classes or 1, images).
 //   class mode: block (c, b) owns the positions of class c in keys2 (sorted by class, then rank);
 //   whole mode (agnostic, or an image whose coordinate range does not rule out cross-class overlap):
@@ -347,7 +416,8 @@ template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restrict__ det, const u64* __restrict__ keys2,
                                                            int m_pad, int m_cap, const int* __restrict__ counts,
                                                            int cap, int max_nms, const img_range* __restrict__ range,
-                                                           int agnostic, float max_wh, float thr, int max_det,
+                                                           const int2* __restrict__ seg_all, int agnostic, float max_wh,
+                                                           float thr, int max_det,
                                                            unsigned char* __restrict__ keep, float4* __restrict__ kept_spill)
 {
     const int b = blockIdx.y;
@@ -367,8 +437,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
         if (blockIdx.x != 0) return;
         s = 0; e = m;
     } else {
-        s = lower_bound_key(k2, m, (u64)blockIdx.x << 32);
-        e = lower_bound_key(k2, m, ((u64)blockIdx.x + 1) << 32);
+        const int2 sg = seg_all[(size_t)b * gridDim.x + blockIdx.x];
+        s = sg.x; e = sg.y;
         if (s >= e) return;
     }
     const float* __restrict__ dimg = det + (size_t)b * m_cap * 6;
@@ -378,6 +448,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
     __shared__ float4 kbox[KEPT_LDS];
     __shared__ float karea[KEPT_LDS];
     __shared__ u64 sup_mask[WAVES];
+    __shared__ float4 cbox[64];      // the 64 candidates of the current chunk
+    __shared__ float carea[64];
+    __shared__ u64 cmask[64];
     __shared__ int s_kept;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float off_scale = agnostic ? 0.0f : max_wh;
@@ -407,36 +480,45 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
         }
         const u64 sm = __ballot(sup);
         if (lane == 0) sup_mask[wave] = sm;
+        if (wave == 0) { cbox[lane] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2); carea[lane] = area; }
         __syncthreads();
-        // phase 2: wave 0 resolves the chunk in score order with ballot masks
+        // phase 2a: all waves build the chunk's 64x64 suppression bit matrix, 64/WAVES rows each
+        // (row i = candidates j > i that box i would suppress)
+#pragma unroll 4
+        for (int q = 0; q < 64 / WAVES; ++q) {
+            const int i = wave * (64 / WAVES) + q;
+            const float4 bi4 = cbox[i];
+            const box_t bi = {bi4.x, bi4.y, bi4.z, bi4.w};
+            const bool hit = (lane > i) && suppresses(bi, carea[i], bx, area, thr);
+            const u64 hm = __ballot(hit);
+            if (lane == 0) cmask[i] = hm;
+        }
+        __syncthreads();
+        // phase 2b: wave 0 walks the chunk in score order with scalar mask arithmetic
         if (wave == 0) {
             u64 dead = 0;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) dead |= sup_mask[w];
             u64 todo = __ballot(valid) & ~dead;
-            while (todo && kept < max_det) {
-                const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
-                todo &= todo - 1;
-                box_t bi;
-                bi.x1 = __shfl(bx.x1, i, 64); bi.y1 = __shfl(bx.y1, i, 64);
-                bi.x2 = __shfl(bx.x2, i, 64); bi.y2 = __shfl(bx.y2, i, 64);
-                const float ai = __shfl(area, i, 64);
-                const bool hit = (lane > i) && suppresses(bi, ai, bx, area, thr);
-                todo &= ~__ballot(hit);
-                if (lane == i) {
-                    kimg[rank] = 1;
-                    const float4 v = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
-                    if (kept < KEPT_LDS) { kbox[kept] = v; karea[kept] = area; }
-                    else spill[kept] = v;
-                }
-                ++kept;
+            u64 kept_mask = 0;
+            int room = max_det - kept;
+            while (todo && room > 0) {
+                const int i = __ffsll((long long)todo) - 1;
+                kept_mask |= 1ull << i;
+                todo &= ~(cmask[i] | (1ull << i));
+                --room;
             }
-            if (lane == 0) s_kept = kept;
-            __threadfence_block();
+            if ((kept_mask >> lane) & 1ull) {
+                const int slot = kept + __popcll(kept_mask & lanemask_lt());
+                kimg[rank] = 1;
+                const float4 v = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+                if (slot < KEPT_LDS) { kbox[slot] = v; karea[slot] = area; }
+                else spill[slot] = v;
+            }
+            if (lane == 0) s_kept = kept + __popcll(kept_mask);
         }
         __syncthreads();
         kept = s_kept;
-        __syncthreads();
     }
 }
 
@@ -504,7 +586,8 @@ __global__ void __launch_bounds__(256) k_nms_plain_gather(const float* __restric
 
 struct nms_layout {
     int cap_pad, m_cap, m_pad;
-    size_t off_counts, off_range, off_keys, off_keys2, off_det, off_keep, off_spill, total;
+    size_t off_counts, off_range, off_seg, off_keys, off_keys2, off_det, off_keep, off_spill, total;
+    size_t zero_bytes;   // [off_seg, off_seg + zero_bytes) = segment table + keep flags, cleared by one memset
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -516,7 +599,7 @@ uint32_t pow2_ceil_host(uint32_t n)
     return p;
 }
 
-nms_layout make_layout(int bs, int cap, int max_nms)
+nms_layout make_layout(int bs, int cap, int max_nms, int nc)
 {
     nms_layout L;
     L.cap_pad = (int)pow2_ceil_host((uint32_t)(cap < 2 ? 2 : cap));
@@ -526,7 +609,9 @@ nms_layout make_layout(int bs, int cap, int max_nms)
     size_t o = 0;
     L.off_counts = o; o = align_up(o + sizeof(int) * bs, 256);
     L.off_range = o; o = align_up(o + sizeof(img_range) * bs, 256);
+    L.off_seg = o; o = align_up(o + sizeof(int2) * (size_t)bs * nc, 256);
     L.off_keep = o; o = align_up(o + (size_t)bs * L.m_cap, 256);
+    L.zero_bytes = o - L.off_seg;
     L.off_keys = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.cap_pad, 256);
     L.off_keys2 = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.m_pad, 256);
     L.off_det = o; o = align_up(o + sizeof(float) * 6 * (size_t)bs * L.m_cap, 256);
@@ -556,10 +641,10 @@ float round_down_to_float(double t)
 
 }  // namespace
 
-extern "C" size_t dh_nms_workspace(int bs, int cap, int max_nms)
+extern "C" size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms)
 {
-    if (bs <= 0 || cap <= 0 || max_nms <= 0) return 0;
-    return make_layout(bs, cap, max_nms).total;
+    if (bs <= 0 || nc <= 0 || cap <= 0 || max_nms <= 0) return 0;
+    return make_layout(bs, cap, max_nms, nc).total;
 }
 
 extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres,
@@ -571,12 +656,13 @@ extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double c
     if ((long long)A * nc >= (1ll << 32)) return DH_ERR_ARG;
     if (bs == 0) return DH_OK;
     if (!pred || !out || !out_count || !cand_count || !workspace) return DH_ERR_ARG;
-    const nms_layout L = make_layout(bs, cap, max_nms);
+    const nms_layout L = make_layout(bs, cap, max_nms, nc);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
     int* counts = (int*)(ws + L.off_counts);
     img_range* range = (img_range*)(ws + L.off_range);
+    int2* seg = (int2*)(ws + L.off_seg);
     unsigned char* keep = (unsigned char*)(ws + L.off_keep);
     u64* keys = (u64*)(ws + L.off_keys);
     u64* keys2 = (u64*)(ws + L.off_keys2);
@@ -587,25 +673,28 @@ extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double c
     const float thr = round_down_to_float(iou_thres);
 
     hipLaunchKernelGGL(k_nms_init, dim3((bs + 255) / 256), dim3(256), 0, st, counts, range, bs);
-    if (hipMemsetAsync(keep, 0, (size_t)bs * L.m_cap, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (hipMemsetAsync(ws + L.off_seg, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
     int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks
     const int gx_cap = 8192 / bs > 1 ? 8192 / bs : 1;
     if (gx > gx_cap) gx = gx_cap;
-    if (multi_label)
-        hipLaunchKernelGGL(k_nms_prefilter<true>, dim3(gx, bs), dim3(256), 0, st, pred, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
-    else
-        hipLaunchKernelGGL(k_nms_prefilter<false>, dim3(gx, bs), dim3(256), 0, st, pred, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
-    hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys, counts, cap, L.cap_pad);
+#define DH_PREFILTER(M, N) hipLaunchKernelGGL((k_nms_prefilter<M, N>), dim3(gx, bs), dim3(256), 0, st, pred, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
+    if (multi_label) {
+        if (nc <= 64) DH_PREFILTER(true, 1); else if (nc <= 128) DH_PREFILTER(true, 2); else DH_PREFILTER(true, 0);
+    } else {
+        if (nc <= 64) DH_PREFILTER(false, 1); else if (nc <= 128) DH_PREFILTER(false, 2); else DH_PREFILTER(false, 0);
+    }
+#undef DH_PREFILTER
+    hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys, counts, cap, L.cap_pad, (int2*)nullptr, 0);
     hipLaunchKernelGGL(k_nms_gather, dim3((L.m_cap + 255) / 256, bs), dim3(256), 0, st, pred, A, dh_make_fastdiv((uint32_t)nc),
                        keys, L.cap_pad, counts, cap, max_nms, det, keys2, L.m_pad, L.m_cap, range);
     if (!agnostic) {
         // keys2 holds m = min(n, max_nms) entries per image; k_sort_keys clamps to `limit`
-        hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys2, counts, L.m_cap, L.m_pad);
+        hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys2, counts, L.m_cap, L.m_pad, seg, nc);
         hipLaunchKernelGGL(k_nms_greedy<4>, dim3(nc, bs), dim3(256), 0, st, det, keys2, L.m_pad, L.m_cap, counts, cap,
-                           max_nms, range, 0, (float)max_wh, thr, max_det, keep, spill);
+                           max_nms, range, seg, 0, (float)max_wh, thr, max_det, keep, spill);
     } else {
         hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, bs), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, counts, cap,
-                           max_nms, range, 1, (float)max_wh, thr, max_det, keep, spill);
+                           max_nms, range, seg, 1, (float)max_wh, thr, max_det, keep, spill);
     }
     hipLaunchKernelGGL(k_nms_collect, dim3(bs), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, cap, max_nms,
                        max_det, out, (long long*)nullptr, out_count);
@@ -616,7 +705,7 @@ extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double c
 extern "C" size_t dh_nms_plain_workspace(int64_t n)
 {
     if (n <= 0 || n >= (1ll << 31)) return 0;
-    return make_layout(1, (int)n, (int)n).total;
+    return make_layout(1, (int)n, (int)n, 1).total;
 }
 
 extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
@@ -627,7 +716,7 @@ extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, 
     if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
     if (!boxes || !scores || !keep_index || !workspace) return DH_ERR_ARG;
     const int ni = (int)n;
-    const nms_layout L = make_layout(1, ni, ni);
+    const nms_layout L = make_layout(1, ni, ni, 1);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
@@ -640,10 +729,10 @@ extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, 
     float4* spill = (float4*)(ws + L.off_spill);
     if (hipMemsetAsync(keep, 0, (size_t)L.m_cap, st) != hipSuccess) return DH_ERR_LAUNCH;
     hipLaunchKernelGGL(k_nms_plain_keys, dim3((ni + 255) / 256), dim3(256), 0, st, scores, ni, keys, counts);
-    hipLaunchKernelGGL(k_sort_keys, dim3(1), dim3(SORT_THREADS), 0, st, keys, counts, ni, L.cap_pad);
+    hipLaunchKernelGGL(k_sort_keys, dim3(1), dim3(SORT_THREADS), 0, st, keys, counts, ni, L.cap_pad, (int2*)nullptr, 0);
     hipLaunchKernelGGL(k_nms_plain_gather, dim3((ni + 255) / 256), dim3(256), 0, st, boxes, keys, ni, det);
     hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, 1), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, counts, ni, ni, range,
-                       1, 0.0f, round_down_to_float(iou_thres), ni, keep, spill);
+                       (const int2*)nullptr, 1, 0.0f, round_down_to_float(iou_thres), ni, keep, spill);
     hipLaunchKernelGGL(k_nms_collect, dim3(1), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, ni, ni, ni,
                        (float*)nullptr, (long long*)keep_index, keep_count);
     return dh_launch_status();

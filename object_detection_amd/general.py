@@ -132,7 +132,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     counts = torch.empty((2, bs), dtype=torch.int32, device=dev)                    # [kept rows, candidates found]
     cap = A
     while True:
-        ws_bytes = lib.dh_nms_workspace(bs, cap, MAX_NMS)
+        ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
         ws = L.workspace(ws_bytes, dev)
         with torch.cuda.device(dev):
             L.check(lib.dh_nms_batched(L.ptr(pred), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),

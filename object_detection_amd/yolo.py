@@ -5,6 +5,24 @@ import torch.nn as nn
 from . import _lib as L
 
 
+_ANCHOR_CACHE = {}
+
+
+def _anchor_pixels(anchors, stride):
+    """Host copies of anchor_grid (= anchors[i] * stride[i], yolo.py:79, formed in fp32 like the reference)
+    and of the strides; cached per anchors tensor version so the steady state does no device-to-host copy."""
+    key = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), id(stride))
+    hit = _ANCHOR_CACHE.get(key)
+    if hit is None:
+        anc = anchors.detach().float().cpu()
+        strd = torch.as_tensor(stride).detach().float().cpu()
+        hit = (L.float_array((anc * strd.view(-1, 1, 1)).reshape(-1).tolist()), L.float_array(strd.tolist()))
+        if len(_ANCHOR_CACHE) > 64:
+            _ANCHOR_CACHE.clear()
+        _ANCHOR_CACHE[key] = hit
+    return hit
+
+
 def detect_decode(levels, anchors, stride):
     """Inference decode of raw head maps -> (bs, sum na*ny*nx, no)  (yolo.py:56-70).
 
@@ -20,16 +38,12 @@ def detect_decode(levels, anchors, stride):
     ny = [int(x.shape[2]) for x in xs]
     nx = [int(x.shape[3]) for x in xs]
     total = sum(na * a * b for a, b in zip(ny, nx))
-    # anchor_grid of yolo.py:79: anchors[i] * stride[i], formed in fp32 exactly as the reference does
-    anc = anchors.detach().float().cpu()
-    strd = torch.as_tensor(stride).detach().float().cpu()
-    anchor_px = (anc * strd.view(-1, 1, 1)).reshape(-1).tolist()
+    anchor_px, strides = _anchor_pixels(anchors, stride)
     out = torch.empty((bs, total, no), dtype=torch.float32, device=xs[0].device)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
     with torch.cuda.device(out.device):
-        L.check(L.lib().dh_yolo_decode(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no,
-                                       L.float_array(anchor_px), L.float_array(strd.tolist()), L.ptr(out), L.stream()),
-                "dh_yolo_decode")
+        L.check(L.lib().dh_yolo_decode(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
+                                       L.ptr(out), L.stream()), "dh_yolo_decode")
     return out
 
 

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Per-stage device timings (HIP events around back-to-back launches) for kernel tuning.
+
+  python tools/time_kernels.py [--batch 64] [--iters 50] [--only decode,loss,nms,centernet]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def timed(fn, iters, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3   # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--only", default="decode,loss,nms,centernet")
+    args = ap.parse_args()
+    only = set(args.only.split(","))
+    dev = torch.device("cuda", 0)
+    from object_detection_amd.general import non_max_suppression
+    from object_detection_amd.loss import masked_ciou_loss
+    from object_detection_amd.yolo import detect_decode
+    from object_detection_amd.yolo_loss import ComputeLoss
+
+    bs, img, nc = args.batch, 640, 80
+    anchors = bench.grid_anchors(dev)
+    crit = ComputeLoss(bench._Model(anchors, nc))
+    levels, targets = bench.synth_batch(bs, img, nc, 10 * bs, 1000, dev)
+    bench.plant_objects(levels, targets, crit)
+    strides = torch.tensor([8., 16., 32.])
+    A = 25200
+    if "decode" in only:
+        us = timed(lambda: detect_decode(levels, anchors, strides), args.iters)
+        print(f"decode            {us:9.1f} us   {680.0 * A * bs / us / 1e3:8.1f} GB/s (680 B/anchor)")
+    z = detect_decode(levels, anchors, strides)
+    if "loss" in only:
+        p = [x.requires_grad_(True) for x in levels]
+        us = timed(lambda: crit(p, targets), args.iters)
+        print(f"assign+loss fwd   {us:9.1f} us")
+
+        def fb():
+            loss, _ = crit(p, targets)
+            torch.autograd.grad(loss, p)
+        us2 = timed(fb, args.iters)
+        print(f"assign+loss f+b   {us2:9.1f} us   bwd alone ~{us2 - us:8.1f} us  {348.0 * A * bs / (us2 - us) / 1e3:8.1f} GB/s (348 B/anchor)")
+    if "nms" in only:
+        us = timed(lambda: non_max_suppression(z, 0.25, 0.45, max_det=300), args.iters)
+        print(f"nms 0.25/0.45     {us:9.1f} us")
+        us = timed(lambda: non_max_suppression(z, 0.001, 0.6, multi_label=True, max_det=300), args.iters)
+        print(f"nms 0.001/0.6 ml  {us:9.1f} us")
+    if "centernet" in only:
+        B, W, H = bs, 160, 160
+        g = torch.Generator(device=dev).manual_seed(3)
+        mask = (torch.rand((B, W, H), generator=g, device=dev) < 0.005).float()
+        ls = torch.rand((B, 2, W, H), generator=g, device=dev) * 20 * mask[:, None]
+        lo = torch.rand((B, 2, W, H), generator=g, device=dev) * mask[:, None]
+        ps = (torch.rand((B, 2, W, H), generator=g, device=dev) * 20).requires_grad_(True)
+        po = torch.rand((B, 2, W, H), generator=g, device=dev).requires_grad_(True)
+        cells = B * W * H
+        us = timed(lambda: masked_ciou_loss(po, ps, lo, ls, mask, add_coords=True), args.iters)
+        print(f"centernet loss fwd sparse {us:9.1f} us  {36.0 * cells / us / 1e3:8.1f} GB/s (36 B/cell)")
+
+        def fb2():
+            v = masked_ciou_loss(po, ps, lo, ls, mask, add_coords=True)
+            torch.autograd.grad(v, [ps, po])
+        us2 = timed(fb2, args.iters)
+        print(f"centernet loss f+b sparse {us2:9.1f} us  bwd ~{us2 - us:8.1f} us {52.0 * cells / (us2 - us) / 1e3:8.1f} GB/s (52 B/cell)")
+        dense = torch.ones_like(mask)
+        us = timed(lambda: masked_ciou_loss(po, ps, lo + 1, ls + 1, dense, add_coords=True), args.iters)
+        print(f"centernet loss fwd dense  {us:9.1f} us  {36.0 * cells / us / 1e3:8.1f} GB/s (36 B/cell)")
+
+
+if __name__ == "__main__":
+    main()
