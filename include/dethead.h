@@ -134,6 +134,29 @@ int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl
                      int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_p,
                      const void* workspace, size_t workspace_bytes, void* stream);
 
+/* N x M IoU of xyxy boxes, no eps (object_detection/yolov5/utils/metrics.py:242-264) and of
+ * (w,h) pairs (metrics.py:291-296).  out is (N,M) row-major. */
+int dh_box_iou(const float* box1, const float* box2, float* out, int64_t N, int64_t M, void* stream);
+int dh_wh_iou(const float* wh1, const float* wh2, float* out, int64_t N, int64_t M, void* stream);
+
+/* pool_nms (object_detection/detectors/centernet/dataset.py:164-169) over `planes` (W,H) maps:
+ * out = heat where heat equals its kernel x kernel neighbourhood maximum, heat*0 elsewhere. */
+int dh_centernet_pool_nms(const float* heat, float* out, int64_t planes, int W, int H, int kernel, void* stream);
+
+/* decode_bbox (dataset.py:172-216): heat (B,C,W,H), size/offset (B,2,W,H) ->
+ * det (B, W*H, 6) rows [x1,y1,x2,y2,conf,cls] (normalised, in cell order) and counts (B). */
+size_t dh_centernet_decode_workspace(int B, int W, int H);
+int dh_centernet_decode(const float* heat, const float* size, const float* offset, int B, int C, int W, int H,
+                        double confidence, float* det, int* counts, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* Target maps of CenternetDataset.__getitem__ (dataset.py:103-150) for a batch: labels (B,Lmax,5)
+ * [x1,y1,x2,y2,cls] in input pixels with nlabels (B) valid rows each; outputs t_cls (B,C,W,H),
+ * t_size / t_offset (B,2,W,H), t_mask (B,W,H); owner_ws is B*W*H ints of scratch.  All device memory. */
+int dh_centernet_targets(const float* labels, const int* nlabels, int B, int Lmax, double input_w, double input_h, int C,
+                         int W, int H, float* t_cls, float* t_size, float* t_offset, float* t_mask, int* owner_ws,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

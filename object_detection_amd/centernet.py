@@ -1,11 +1,125 @@
 """Drop-ins for the CenterNet head glue.
 
   object_detection/detectors/centernet/loss.py:4-28        offset_to_coord, compute_losses
+  object_detection/detectors/centernet/dataset.py:96-161   target maps (batched, on the device)
+  object_detection/detectors/centernet/dataset.py:164-297  pool_nms, decode_bbox, postprocess, postprocess_predictions
 """
+import numpy as np
 import torch
 
 from . import _lib as L
 from .loss import IoULossWithMask, masked_ciou_loss
+from .ops import nms
+
+
+def pool_nms(heat, kernel=3):
+    """heat (B,C,W,H) -> heat * (maxpool_kxk(heat) == heat)  (dataset.py:164-169)."""
+    h = L.dev_f32(heat, "heat").contiguous()
+    if h.dim() != 4:
+        raise RuntimeError(f"pool_nms: expected (B,C,W,H), got {tuple(heat.shape)}")
+    out = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        L.check(L.lib().dh_centernet_pool_nms(L.ptr(h), L.ptr(out), h.shape[0] * h.shape[1], h.shape[2], h.shape[3],
+                                              int(kernel), L.stream()), "dh_centernet_pool_nms")
+    return out
+
+
+def decode_bbox(pred_cls, pred_size, pred_offset, confidence, device=None):
+    """Per image: [] or (k,6) [x1,y1,x2,y2,conf,cls] normalised boxes in cell order (dataset.py:172-216).
+
+    Peak filter, tanh, best class and thresholding run in two launches for the whole batch; one
+    host copy of the per-image counts replaces the reference's per-image loop.
+    """
+    heat = L.dev_f32(pred_cls, "pred_cls").contiguous()
+    size = L.dev_f32(pred_size, "pred_size").contiguous()
+    off = L.dev_f32(pred_offset, "pred_offset").contiguous()
+    B, C, W, H = heat.shape
+    if tuple(size.shape) != (B, 2, W, H) or tuple(off.shape) != (B, 2, W, H):
+        raise RuntimeError("decode_bbox: size/offset maps must be (B,2,W,H) matching the class map")
+    lib = L.lib()
+    ws_bytes = lib.dh_centernet_decode_workspace(B, W, H)
+    ws = L.workspace(ws_bytes, heat.device)
+    det = torch.empty((B, W * H, 6), dtype=torch.float32, device=heat.device)
+    counts = torch.empty(B, dtype=torch.int32, device=heat.device)
+    with torch.cuda.device(heat.device):
+        L.check(lib.dh_centernet_decode(L.ptr(heat), L.ptr(size), L.ptr(off), B, C, W, H, float(confidence), L.ptr(det),
+                                        L.ptr(counts), L.ptr(ws), ws_bytes, L.stream()), "dh_centernet_decode")
+    return [det[i, :k] if k else [] for i, k in enumerate(counts.tolist())]
+
+
+def centernet_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image):
+    """dataset.py:219-243.  numpy in, numpy out: the reference does this step on the host after .cpu()."""
+    input_shape = np.array(input_shape)
+    image_shape = np.array(image_shape)
+    if letterbox_image:
+        new_shape = np.round(image_shape * np.min(input_shape / image_shape))
+        offset = (input_shape - new_shape) / 2.0 / input_shape
+        scale = input_shape / new_shape
+        box_xy = (box_xy - offset) * scale
+        box_wh *= scale
+    box_mins = box_xy - (box_wh / 2.0)
+    box_maxes = box_xy + (box_wh / 2.0)
+    boxes = np.concatenate([box_mins[..., 0:1], box_mins[..., 1:2], box_maxes[..., 0:1], box_maxes[..., 1:2]], axis=-1)
+    boxes *= image_shape
+    return boxes
+
+
+def postprocess(prediction, need_nms, image_shape, input_shape, letterbox_image, nms_thres=0.4):
+    """dataset.py:246-284 -> list of numpy (k,6) arrays or None; rows grouped by ascending class,
+    inside a class in score order when need_nms else in input order."""
+    output = [None for _ in range(len(prediction))]
+    for i, det in enumerate(prediction):
+        if len(det) == 0:
+            continue
+        for c in det[:, -1].unique():
+            same = det[det[:, -1] == c]
+            if need_nms:
+                same = same[nms(same[:, :4], same[:, 4], nms_thres)]
+            output[i] = same if output[i] is None else torch.cat((output[i], same))
+        if output[i] is not None:
+            arr = output[i].cpu().detach().numpy()
+            box_xy, box_wh = (arr[:, 0:2] + arr[:, 2:4]) / 2, arr[:, 2:4] - arr[:, 0:2]
+            arr[:, :4] = centernet_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image)
+            output[i] = arr
+    return output
+
+
+def postprocess_predictions(pred, image_size, device=None):
+    """dataset.py:287-297: confidence 0.9, no NMS, input_shape = image_size / 4."""
+    outputs = decode_bbox(pred[0], pred[1], pred[2], confidence=0.9, device=device)
+    return postprocess(outputs, need_nms=False, image_shape=image_size, input_shape=image_size / 4,
+                       letterbox_image=False, nms_thres=0.4)
+
+
+def centernet_targets(labels, num_classes, input_shape, output_shape, device=None):
+    """Target maps of CenternetDataset.__getitem__ (dataset.py:103-150) for a whole batch on the device.
+
+    labels: list of (n_i,5) arrays/tensors [x1,y1,x2,y2,cls] in input pixels.
+    Returns (cls (B,C,W,H), size (B,2,W,H), offset (B,2,W,H), mask (B,W,H)), what the reference's
+    DataLoader workers build one sample at a time in numpy.
+    """
+    B = len(labels)
+    dev = torch.device(device) if device is not None else next(
+        (l.device for l in labels if isinstance(l, torch.Tensor) and l.is_cuda), torch.device("cuda"))
+    W, H = int(output_shape[0]), int(output_shape[1])
+    lmax = max((len(l) for l in labels), default=0)
+    packed = torch.zeros((B, max(lmax, 1), 5), dtype=torch.float32)
+    for i, l in enumerate(labels):
+        if len(l):
+            packed[i, :len(l)] = torch.as_tensor(np.asarray(l.cpu() if isinstance(l, torch.Tensor) else l)[:, :5],
+                                                 dtype=torch.float32)
+    nl = torch.tensor([len(l) for l in labels], dtype=torch.int32)
+    packed, nl = packed.to(dev), nl.to(dev)
+    t_cls = torch.empty((B, num_classes, W, H), dtype=torch.float32, device=dev)
+    t_size = torch.empty((B, 2, W, H), dtype=torch.float32, device=dev)
+    t_off = torch.empty((B, 2, W, H), dtype=torch.float32, device=dev)
+    t_mask = torch.empty((B, W, H), dtype=torch.float32, device=dev)
+    owner = torch.empty((B, W, H), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        L.check(L.lib().dh_centernet_targets(L.ptr(packed), L.ptr(nl), B, lmax, float(input_shape[0]), float(input_shape[1]),
+                                             int(num_classes), W, H, L.ptr(t_cls), L.ptr(t_size), L.ptr(t_off),
+                                             L.ptr(t_mask), L.ptr(owner), L.stream()), "dh_centernet_targets")
+    return t_cls, t_size, t_off, t_mask
 
 
 def offset_to_coord(pred):

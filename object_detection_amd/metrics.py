@@ -62,6 +62,28 @@ def bbox_iou(box1, box2, x1y1x2y2=True, GIoU=False, DIoU=False, CIoU=False, eps=
     return _PairIoU.apply(box1, box2, 0, 1, x1y1x2y2, _mode(GIoU, DIoU, CIoU), eps)
 
 
+def _pairwise(name, a, b, width):
+    a = L.dev_f32(a, "box1").contiguous()
+    b = L.dev_f32(b, "box2").contiguous()
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != width or b.shape[1] != width:
+        raise RuntimeError(f"{name}: expected (N,{width}) and (M,{width}), got {tuple(a.shape)} and {tuple(b.shape)}")
+    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        L.check(getattr(L.lib(), "dh_" + name)(L.ptr(a), L.ptr(b), L.ptr(out), a.shape[0], b.shape[0], L.stream()),
+                "dh_" + name)
+    return out
+
+
+def box_iou(box1, box2):
+    """(N,4) x (M,4) xyxy boxes -> (N,M) IoU matrix (metrics.py:242-264)."""
+    return _pairwise("box_iou", box1, box2, 4)
+
+
+def wh_iou(wh1, wh2):
+    """(N,2) x (M,2) width/height pairs -> (N,M) IoU matrix (metrics.py:291-296)."""
+    return _pairwise("wh_iou", wh1, wh2, 2)
+
+
 def bbox_ioa(box1, box2, eps=1E-7):
     """Intersection over box2 area, numpy in / numpy out (metrics.py:267-288).
 
