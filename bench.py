@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="EXPERIMENTAL: replay one captured HIP graph per stage instead of launching from Python")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -146,8 +148,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
 
-    from object_detection_amd.dist import all_reduce_loss_stats
-    from object_detection_amd.general import non_max_suppression
     from object_detection_amd.yolo import detect_decode
     from object_detection_amd.yolo_loss import ComputeLoss
 
@@ -160,26 +160,48 @@ def main():
     A = sum(3 * (img // s) ** 2 for s in STRIDES)
     p = [x.requires_grad_(True) for x in levels]
 
-    stages = ("decode", "assign+loss_fwd", "loss_bwd", "nms", "allreduce")
+    from object_detection_amd.dist import pack_loss_stats
+    from object_detection_amd.general import nms_finish, nms_launch
+    from object_detection_amd.graphs import GraphedStage
+
+    use_graph = args.graph
+    stages = ("decode", "assign+loss_fwd+bwd", "nms", "allreduce+host")
     ev = {s: [] for s in stages}
+    cap = A
+
+    def f_decode():
+        with torch.no_grad():
+            return detect_decode(levels, anchors, strides)
+
+    def f_loss():
+        if use_graph:      # same kernels, called without the autograd engine (which cannot be captured reliably)
+            loss, items, grads = crit.forward_backward(p, targets)
+        else:
+            loss, items = crit(p, targets)
+            grads = torch.autograd.grad(loss, p)
+        return loss, items, grads, pack_loss_stats(items, crit.last_positive_counts)
+
+    if use_graph:   # one HIP graph per stage so that events between replays still bracket each stage
+        g_decode = GraphedStage(f_decode)
+        z_static = g_decode.outputs
+        g_loss = GraphedStage(f_loss)
+        g_decode.replay()      # give the NMS warm-up real predictions to work on
+        g_nms = GraphedStage(lambda: nms_launch(z_static, 0.25, 0.45, max_det=300, cap=cap))
 
     def step(record):
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if record else None
         if record: marks[0].record()
-        with torch.no_grad():
-            z = detect_decode(levels, anchors, strides)
+        z = g_decode.replay() if use_graph else f_decode()
         if record: marks[1].record()
-        loss, items = crit(p, targets)
+        loss, items, grads, stats = g_loss.replay() if use_graph else f_loss()
         if record: marks[2].record()
-        grads = torch.autograd.grad(loss, p)
+        rows, meta, _ = g_nms.replay() if use_graph else nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
         if record: marks[3].record()
-        dets = non_max_suppression(z, 0.25, 0.45, max_det=300)
+        if world > 1:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)          # [lbox, lobj, lcls, n_pos] over RCCL
+        dets, _ = nms_finish(rows, meta, cap)                    # the step's only device-to-host copy (3*bs ints)
         if record: marks[4].record()
-        stats = all_reduce_loss_stats(items, crit.last_positive_counts)
-        if record:
-            marks[5].record()
-            return marks, dets, loss, grads, stats
-        return None, dets, loss, grads, stats
+        return marks, dets, loss, grads, stats
 
     def sync_all():
         if world > 1:
@@ -217,9 +239,6 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc.get("k_yolo_decode_bytes_per_launch"),
                 "algorithmic_bytes_per_launch": decode_bytes, "avg_launch_ms": round(stage_ms["decode"], 4)}
-    bwd_bytes = (340.0 + 4.0 + 4.0) * A * bs        # dense gradient write + obj logit + owner word per anchor
-    extra_kernels = {"loss_bwd_dense": {"algorithmic_GBps": round(bwd_bytes / (stage_ms["loss_bwd"] * 1e-3) / 1e9, 1),
-                                        "frac_of_peak": round(bwd_bytes / (stage_ms["loss_bwd"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
     if rank == 0:
         line = {
@@ -232,7 +251,8 @@ def main():
                        "global_batch": bs * world, "parallelism": f"image-sharded x{world}",
                        "planted_positive_rows": n_planted, "detections_last_step": int(sum(d.shape[0] for d in dets))},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": roofline, "other_kernels": extra_kernels,
+            "launch_mode": "hip-graph per stage" if use_graph else "eager",
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -68,17 +68,19 @@ int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx,
 
 /* Batched non_max_suppression (object_detection/yolov5/utils/general.py:647-738) over
  * pred (bs, A, 5+nc) = [x,y,w,h,obj,cls...].  Output rows are [x1,y1,x2,y2,conf,cls] in the
- * reference's order (score descending; equal scores in candidate order), out is (bs,max_det,6),
- * out_count (bs) the rows valid per image, cand_count (bs) the candidates found per image:
- * cand_count[b] > cap means the per-image candidate capacity overflowed and the call must be
- * repeated with a larger cap (only possible with multi_label; cap = A always suffices otherwise).
+ * reference's order (score descending; equal scores in candidate order).  The rows of all images are
+ * packed back to back in out (room for bs*max_det rows of 6 floats); out_span (bs pairs of ints) gives
+ * each image's {first row, row count} (images are packed in completion order, not index order).
+ * cand_count (bs) is the number of candidates found per image: cand_count[b] > cap means the per-image
+ * candidate capacity overflowed and the call must be repeated with a larger cap (only possible with
+ * multi_label; cap = A always suffices otherwise).
  * class_keep: nc bytes on the device (1 = keep class) or NULL (general.py:705-706).
- * max_nms = 30000 and max_wh = 7680 in the reference (general.py:663-664).  All of out,
- * out_count, cand_count, workspace are device memory; workspace must be 256-byte aligned. */
+ * max_nms = 30000 and max_wh = 7680 in the reference (general.py:663-664).  All of out, out_span,
+ * cand_count, workspace are device memory; workspace must be 256-byte aligned. */
 size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms);
 int dh_nms_batched(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres, int multi_label,
                    int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
-                   float* out, int* out_count, int* cand_count, void* workspace, size_t workspace_bytes, void* stream);
+                   float* out, int* out_span, int* cand_count, void* workspace, size_t workspace_bytes, void* stream);
 
 /* torchvision.ops.nms(boxes[n,4] xyxy, scores[n], iou_threshold) as called at
  * object_detection/yolov5/utils/general.py:722 and object_detection/detectors/centernet/dataset.py:263:

@@ -6,6 +6,8 @@
 // Per image the output is one contiguous span and each level's input is one contiguous span, so
 // the kernel is a pure stream: 16-byte loads and stores, 680 B of HBM traffic per anchor, and the
 // reference's separate sigmoid / slice-assign / torch.cat passes collapse into this single pass.
+#include <stdlib.h>
+
 #include "dh_common.h"
 #include "../../include/dethead.h"
 
@@ -48,9 +50,7 @@ __device__ __forceinline__ float decode_box(const decode_level& L, uint32_t row,
 // 4 floats and 16-byte aligned; VEC = 1 is the general fallback.  Every element gets its sigmoid
 // unconditionally; the 4-of-`no` box channels are patched afterwards, once per vector, so the hot
 // path has a single division by `no` and one (rarely taken) branch per 16 bytes.
-#define DH_DEC_UNROLL 4
-
-template <int VEC>
+template <int VEC, int DH_DEC_UNROLL, int NT>
 __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, float* __restrict__ out)
 {
     const int b = blockIdx.y;
@@ -71,7 +71,10 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
 #pragma unroll
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
             const uint32_t v = v0 + u * 256;
-            if (v < nvec) x[u] = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(src + (size_t)v * 4));
+            if (v < nvec) {
+                if (NT & 1) x[u] = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(src + (size_t)v * 4));
+                else x[u] = *reinterpret_cast<const dh_f4*>(src + (size_t)v * 4);
+            }
         }
 #pragma unroll
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
@@ -90,7 +93,8 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
                 }
             }
             const dh_f4 o = {y[0], y[1], y[2], y[3]};
-            *reinterpret_cast<dh_f4*>(dst + (size_t)e) = o;
+            if (NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<dh_f4*>(dst + (size_t)e));
+            else *reinterpret_cast<dh_f4*>(dst + (size_t)e) = o;
         }
     } else {
 #pragma unroll
@@ -136,14 +140,30 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
     }
     P.per_image = (uint32_t)first;
     const int vec = vec4 ? 4 : 1;
+    static int unroll = 0, nt = 0;
+    if (unroll == 0) {   // tuning knobs (defaults are the measured best)
+        const char* u = getenv("DH_DECODE_UNROLL");
+        const char* n = getenv("DH_DECODE_NT");
+        unroll = u ? atoi(u) : 8;
+        nt = n ? atoi(n) : 3;
+        if (unroll != 2 && unroll != 4 && unroll != 8) unroll = 8;
+    }
+    const int per_block = 256 * (vec4 ? unroll : 4);
     uint32_t gx = 0;
     for (int l = 0; l < nl; ++l) {
         const uint32_t nvec = P.lvl[l].elems / vec;
-        P.blocks[l] = (nvec + 256 * DH_DEC_UNROLL - 1) / (256 * DH_DEC_UNROLL);
+        P.blocks[l] = (nvec + per_block - 1) / per_block;
         gx += P.blocks[l];
     }
     hipStream_t st = (hipStream_t)stream;
-    if (vec4) hipLaunchKernelGGL(k_yolo_decode<4>, dim3(gx, bs), dim3(256), 0, st, P, out);
-    else hipLaunchKernelGGL(k_yolo_decode<1>, dim3(gx, bs), dim3(256), 0, st, P, out);
+#define DH_DEC(U, N) hipLaunchKernelGGL((k_yolo_decode<4, U, N>), dim3(gx, bs), dim3(256), 0, st, P, out)
+#define DH_DEC_NT(U) do { if (nt == 0) DH_DEC(U, 0); else if (nt == 1) DH_DEC(U, 1); else if (nt == 2) DH_DEC(U, 2); else DH_DEC(U, 3); } while (0)
+    if (vec4) {
+        if (unroll == 2) DH_DEC_NT(2); else if (unroll == 8) DH_DEC_NT(8); else DH_DEC_NT(4);
+    } else {
+        hipLaunchKernelGGL((k_yolo_decode<1, 4, 0>), dim3(gx, bs), dim3(256), 0, st, P, out);
+    }
+#undef DH_DEC_NT
+#undef DH_DEC
     return dh_launch_status();
 }

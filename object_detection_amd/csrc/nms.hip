@@ -524,42 +524,68 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
 
 // ------------------------------------------------------------------------------------------ 6 collect
 // First max_det kept ranks (ascending rank == descending score) -> out rows (or original indices).
+// Rows of all images are packed back to back: a workgroup first counts its image's rows, reserves
+// [base, base+count) with one atomicAdd on *cursor, then writes; out_span[b] = {base, count}.
+// (cursor == nullptr: single image, base 0.)
 __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ det, const unsigned char* __restrict__ keep,
                                                       const u64* __restrict__ keys, int cap_pad, int m_cap,
                                                       const int* __restrict__ counts, int cap, int max_nms, int max_det,
                                                       float* __restrict__ out, long long* __restrict__ out_index,
-                                                      int* __restrict__ out_count)
+                                                      int* __restrict__ out_count, int* __restrict__ cursor,
+                                                      int2* __restrict__ out_span)
 {
     const int b = blockIdx.x;
     int n = counts[b];
     if (n > cap) n = cap;
     const int m = n < max_nms ? n : max_nms;
     __shared__ int wcount[16];
-    __shared__ int s_total;
+    __shared__ int s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char* __restrict__ kimg = keep + (size_t)b * m_cap;
+    // pass 1: how many rows this image contributes
     int total = 0;
     for (int base = 0; base < m && total < max_det; base += 1024) {
         const int r = base + threadIdx.x;
-        const bool k = r < m && keep[(size_t)b * m_cap + r] != 0;
+        const u64 bm = __ballot(r < m && kimg[r] != 0);
+        if (lane == 0) wcount[wave] = __popcll(bm);
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 16; ++w) total += wcount[w];
+        __syncthreads();
+    }
+    if (total > max_det) total = max_det;
+    if (threadIdx.x == 0) {
+        const int first = cursor ? atomicAdd(cursor, total) : 0;
+        s_base = first;
+        if (out_count) out_count[b] = total;
+        if (out_span) out_span[b] = make_int2(first, total);
+    }
+    __syncthreads();
+    const int first = s_base;
+    // pass 2: write them in rank order
+    int done = 0;
+    for (int base = 0; base < m && done < total; base += 1024) {
+        const int r = base + threadIdx.x;
+        const bool k = r < m && kimg[r] != 0;
         const u64 bm = __ballot(k);
         if (lane == 0) wcount[wave] = __popcll(bm);
         __syncthreads();
         int before = 0, all = 0;
+#pragma unroll
         for (int w = 0; w < 16; ++w) { const int c = wcount[w]; if (w < wave) before += c; all += c; }
-        const int pos = total + before + __popcll(bm & lanemask_lt());
-        if (k && pos < max_det) {
+        const int pos = done + before + __popcll(bm & lanemask_lt());
+        if (k && pos < total) {
             if (out) {
                 const float* __restrict__ d = det + ((size_t)b * m_cap + r) * 6;
-                float* __restrict__ o = out + ((size_t)b * max_det + pos) * 6;
+                float* __restrict__ o = out + ((size_t)first + pos) * 6;
 #pragma unroll
                 for (int q = 0; q < 6; ++q) o[q] = d[q];
             }
-            if (out_index) out_index[(size_t)b * max_det + pos] = (long long)(uint32_t)keys[(size_t)b * cap_pad + r];
+            if (out_index) out_index[(size_t)first + pos] = (long long)(uint32_t)keys[(size_t)b * cap_pad + r];
         }
-        total += all;
+        done += all;
         __syncthreads();
     }
-    if (threadIdx.x == 0) out_count[b] = total < max_det ? total : max_det;
 }
 
 // plain nms(): keys from scores, det rows from boxes
@@ -586,7 +612,7 @@ __global__ void __launch_bounds__(256) k_nms_plain_gather(const float* __restric
 
 struct nms_layout {
     int cap_pad, m_cap, m_pad;
-    size_t off_counts, off_range, off_seg, off_keys, off_keys2, off_det, off_keep, off_spill, total;
+    size_t off_counts, off_range, off_cursor, off_seg, off_keys, off_keys2, off_det, off_keep, off_spill, total;
     size_t zero_bytes;   // [off_seg, off_seg + zero_bytes) = segment table + keep flags, cleared by one memset
 };
 
@@ -609,6 +635,7 @@ nms_layout make_layout(int bs, int cap, int max_nms, int nc)
     size_t o = 0;
     L.off_counts = o; o = align_up(o + sizeof(int) * bs, 256);
     L.off_range = o; o = align_up(o + sizeof(img_range) * bs, 256);
+    L.off_cursor = o; o = align_up(o + sizeof(int), 256);
     L.off_seg = o; o = align_up(o + sizeof(int2) * (size_t)bs * nc, 256);
     L.off_keep = o; o = align_up(o + (size_t)bs * L.m_cap, 256);
     L.zero_bytes = o - L.off_seg;
@@ -620,9 +647,10 @@ nms_layout make_layout(int bs, int cap, int max_nms, int nc)
     return L;
 }
 
-__global__ void k_nms_init(int* counts, img_range* range, int bs)
+__global__ void k_nms_init(int* counts, img_range* range, int* cursor, int bs)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *cursor = 0;
     if (i < bs) {
         counts[i] = 0;
         range[i].lo = 0x7fffffff;       // above every float_order()
@@ -649,13 +677,13 @@ extern "C" size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms)
 
 extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres,
                               int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
-                              int max_nms, double max_wh, int cap, float* out, int* out_count, int* cand_count,
+                              int max_nms, double max_wh, int cap, float* out, int* out_span, int* cand_count,
                               void* workspace, size_t workspace_bytes, void* stream)
 {
     if (bs < 0 || bs > 65535 || A < 1 || nc < 1 || max_det < 1 || max_nms < 1 || cap < 1) return DH_ERR_ARG;
     if ((long long)A * nc >= (1ll << 32)) return DH_ERR_ARG;
     if (bs == 0) return DH_OK;
-    if (!pred || !out || !out_count || !cand_count || !workspace) return DH_ERR_ARG;
+    if (!pred || !out || !out_span || !cand_count || !workspace) return DH_ERR_ARG;
     const nms_layout L = make_layout(bs, cap, max_nms, nc);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
@@ -672,7 +700,8 @@ extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double c
     const float conf = (float)conf_thres;
     const float thr = round_down_to_float(iou_thres);
 
-    hipLaunchKernelGGL(k_nms_init, dim3((bs + 255) / 256), dim3(256), 0, st, counts, range, bs);
+    int* cursor = (int*)(ws + L.off_cursor);
+    hipLaunchKernelGGL(k_nms_init, dim3((bs + 255) / 256), dim3(256), 0, st, counts, range, cursor, bs);
     if (hipMemsetAsync(ws + L.off_seg, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
     int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks
     const int gx_cap = 8192 / bs > 1 ? 8192 / bs : 1;
@@ -697,7 +726,7 @@ extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double c
                            max_nms, range, seg, 1, (float)max_wh, thr, max_det, keep, spill);
     }
     hipLaunchKernelGGL(k_nms_collect, dim3(bs), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, cap, max_nms,
-                       max_det, out, (long long*)nullptr, out_count);
+                       max_det, out, (long long*)nullptr, (int*)nullptr, cursor, (int2*)out_span);
     if (hipMemcpyAsync(cand_count, counts, sizeof(int) * bs, hipMemcpyDeviceToDevice, st) != hipSuccess) return DH_ERR_LAUNCH;
     return dh_launch_status();
 }
@@ -734,6 +763,6 @@ extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, 
     hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, 1), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, counts, ni, ni, range,
                        (const int2*)nullptr, 1, 0.0f, round_down_to_float(iou_thres), ni, keep, spill);
     hipLaunchKernelGGL(k_nms_collect, dim3(1), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, ni, ni, ni,
-                       (float*)nullptr, (long long*)keep_index, keep_count);
+                       (float*)nullptr, (long long*)keep_index, keep_count, (int*)nullptr, (int2*)nullptr);
     return dh_launch_status();
 }

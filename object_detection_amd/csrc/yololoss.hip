@@ -171,43 +171,42 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
 }
 
 // out: [0] loss, [1..3] lbox,lobj,lcls (after gains), [4..4+nl) mean objectness BCE per level, [4+nl] ignored rows
-__global__ void __launch_bounds__(256) k_yl_final(const yl_params P, const int* __restrict__ counts,
-                                                  const float* __restrict__ iou_ws, const float* __restrict__ cls_ws,
-                                                  const double* __restrict__ partial, const int* __restrict__ invalid,
-                                                  float* __restrict__ out)
+#define FINAL_THREADS 1024
+
+__global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, const int* __restrict__ counts,
+                                                            const float* __restrict__ iou_ws, const float* __restrict__ cls_ws,
+                                                            const double* __restrict__ partial, const int* __restrict__ invalid,
+                                                            float* __restrict__ out)
 {
-    __shared__ double red[3][4];
-    __shared__ float s_box[DH_MAX_LEVELS], s_cls[DH_MAX_LEVELS], s_obj[DH_MAX_LEVELS];
+    __shared__ double red[3 * DH_MAX_LEVELS][FINAL_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned first_block = 0;
-    for (int l = 0; l < P.nl; ++l) {
+    for (int l = 0; l < P.nl; ++l) {       // all loads of all levels are independent: no barrier inside the loop
         const int n = counts[l];
         double sb = 0.0, sc = 0.0, so = 0.0;
-        for (int r = threadIdx.x; r < n; r += blockDim.x) {
+        for (int r = threadIdx.x; r < n; r += FINAL_THREADS) {
             sb += (double)(1.0f - iou_ws[(size_t)l * P.cap + r]);
             sc += (double)cls_ws[(size_t)l * P.cap + r];
         }
-        for (unsigned k = threadIdx.x; k < P.lvl[l].blocks; k += blockDim.x) so += partial[first_block + k];
+        for (unsigned k = threadIdx.x; k < P.lvl[l].blocks; k += FINAL_THREADS) so += partial[first_block + k];
         first_block += P.lvl[l].blocks;
         sb = dh_wave_sum_d(sb); sc = dh_wave_sum_d(sc); so = dh_wave_sum_d(so);
-        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = sc; red[2][threadIdx.x >> 6] = so; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const double tb = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-            const double tc = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-            const double to = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-            s_box[l] = n > 0 ? (float)(tb / n) : 0.0f;
-            s_cls[l] = (n > 0 && P.nc > 1) ? (float)(tc / ((double)n * P.nc)) : 0.0f;
-            s_obj[l] = (float)(to / (double)P.lvl[l].cells);
-        }
-        __syncthreads();
+        if (lane == 0) { red[3 * l + 0][wave] = sb; red[3 * l + 1][wave] = sc; red[3 * l + 2][wave] = so; }
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
         float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
         for (int l = 0; l < P.nl; ++l) {
-            lbox += s_box[l];
-            lcls += s_cls[l];
-            lobj += s_obj[l] * P.lvl[l].balance;                                                 // loss.py:156
-            out[4 + l] = s_obj[l];
+            double tb = 0.0, tc = 0.0, to = 0.0;
+            for (int w = 0; w < FINAL_THREADS / 64; ++w) { tb += red[3 * l][w]; tc += red[3 * l + 1][w]; to += red[3 * l + 2][w]; }
+            const int n = counts[l];
+            const float s_box = n > 0 ? (float)(tb / n) : 0.0f;
+            const float s_cls = (n > 0 && P.nc > 1) ? (float)(tc / ((double)n * P.nc)) : 0.0f;
+            const float s_obj = (float)(to / (double)P.lvl[l].cells);
+            lbox += s_box;
+            lcls += s_cls;
+            lobj += s_obj * P.lvl[l].balance;                                                    // loss.py:156
+            out[4 + l] = s_obj;
         }
         lbox *= P.box; lobj *= P.obj; lcls *= P.cls;                                             // loss.py:162-164
         out[0] = (lbox + lobj + lcls) * (float)P.bs;
@@ -399,7 +398,7 @@ extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int*
         hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
                            anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
     hipLaunchKernelGGL(k_yl_obj_fwd, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial);
-    hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(256), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
+    hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(FINAL_THREADS), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
     return dh_launch_status();
 }
 

@@ -95,13 +95,12 @@ def _with_apriori_labels(pred, labels, nc):
     return torch.cat((pred, pad), 1)
 
 
-def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-                        labels=(), max_det=300):
-    """Batched NMS on (bs, A, 5+nc) predictions -> list of (k,6) [xyxy, conf, cls] per image (general.py:647-738).
+def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+               labels=(), max_det=300, cap=None):
+    """Enqueue the whole NMS pipeline; nothing is copied to the host (safe inside HIP graph capture).
 
-    The whole batch is processed by one sequence of kernel launches and a single device-to-host copy
-    of the per-image counts; the returned tensors are views of one (bs, max_det, 6) buffer.
-    The reference's 10 s wall-clock bail-out (general.py:734-736) is not reproduced.
+    Returns (rows, meta, cap): rows (bs*max_det, 6) packed detections, meta int32 [bs x {first row, row
+    count}, bs x candidates found]; pass both to nms_finish.  (None, None, 0) when there is nothing to do.
     """
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
@@ -115,11 +114,9 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         pred = _with_apriori_labels(pred, labels, nc)
     A = pred.shape[1]
     dev = pred.device
-    if bs == 0 or A == 0:
-        return [torch.zeros((0, 6), device=dev)] * bs
     max_det = int(max_det)
-    if max_det < 1:
-        return [torch.zeros((0, 6), device=dev)] * bs
+    if bs == 0 or A == 0 or max_det < 1:
+        return None, None, 0
     keep_mask = None
     if classes is not None:
         flags = torch.zeros(nc, dtype=torch.uint8)
@@ -128,21 +125,50 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
             flags[idx] = 1
         keep_mask = flags.to(dev)
     lib = L.lib()
-    out = torch.empty((bs, max_det, 6), dtype=torch.float32, device=dev)
-    counts = torch.empty((2, bs), dtype=torch.int32, device=dev)                    # [kept rows, candidates found]
-    cap = A
+    cap = A if cap is None else int(cap)
+    rows = torch.empty((bs * max_det, 6), dtype=torch.float32, device=dev)
+    meta = torch.empty(3 * bs, dtype=torch.int32, device=dev)
+    ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
+    ws = L.workspace(ws_bytes, dev)
+    with torch.cuda.device(dev):
+        L.check(lib.dh_nms_batched(L.ptr(pred), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
+                                   int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap,
+                                   L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs), L.ptr(ws),
+                                   ws_bytes, L.stream()), "dh_nms_batched")
+    return rows, meta, cap
+
+
+def nms_finish(rows, meta, cap):
+    """The one device-to-host copy (3*bs ints) and the per-image views.  Returns None if the candidate
+    capacity overflowed (the caller must relaunch with the returned-by-meta larger cap)."""
+    bs = meta.numel() // 3
+    host = meta.tolist()
+    if max(host[2 * bs:]) > cap:
+        return None, max(host[2 * bs:])
+    # images are packed in completion order: one split() call makes every per-image view
+    first, count = host[0:2 * bs:2], host[1:2 * bs:2]
+    order = [i for i in sorted(range(bs), key=first.__getitem__) if count[i]]
+    result = [torch.zeros((0, 6), device=rows.device)] * bs
+    if order:
+        for i, piece in zip(order, rows[:sum(count)].split([count[i] for i in order])):
+            result[i] = piece
+    return result, cap
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=(), max_det=300):
+    """Batched NMS on (bs, A, 5+nc) predictions -> list of (k,6) [xyxy, conf, cls] per image (general.py:647-738).
+
+    The whole batch is processed by one sequence of kernel launches and a single device-to-host copy
+    of the per-image counts; the returned tensors are views of one packed buffer.
+    The reference's 10 s wall-clock bail-out (general.py:734-736) is not reproduced.
+    """
+    cap = None
     while True:
-        ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
-        ws = L.workspace(ws_bytes, dev)
-        with torch.cuda.device(dev):
-            L.check(lib.dh_nms_batched(L.ptr(pred), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
-                                       int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap,
-                                       L.ptr(out), L.ptr(counts[0]), L.ptr(counts[1]), L.ptr(ws), ws_bytes, L.stream()),
-                    "dh_nms_batched")
-        host = counts.cpu()
-        found = int(host[1].max())
-        if found <= cap:
-            break
-        cap = found            # multi-label produced more candidates than rows: rerun with room for all of them
-    empty = torch.zeros((0, 6), device=dev)
-    return [out[i, :k] if k else empty for i, k in enumerate(host[0].tolist())]
+        rows, meta, cap = nms_launch(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det, cap)
+        if rows is None:
+            return [torch.zeros((0, 6), device=prediction.device)] * prediction.shape[0]
+        result, cap = nms_finish(rows, meta, cap)
+        if result is not None:
+            return result
+        # multi-label produced more candidates than rows: rerun with room for all of them

@@ -51,31 +51,52 @@ def _assign(level_shapes, targets, anchors, anchor_t):
     return A
 
 
+def _loss_fwd(assign, hyp, nc, maps):
+    """Launch the forward kernels; returns (out[5+nl], workspace) -- the workspace feeds the backward."""
+    nl = len(maps)
+    bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
+    for x, ny, nx in zip(maps, assign.ny, assign.nx):
+        if tuple(x.shape) != (bs, na, ny, nx, nc + 5):
+            raise RuntimeError(f"ComputeLoss: level shape {tuple(x.shape)} does not match (bs,na,ny,nx,5+nc)")
+    dev = maps[0].device
+    lib = L.lib()
+    ny, nx = L.int_array(assign.ny), L.int_array(assign.nx)
+    ws_bytes = lib.dh_yolo_loss_workspace(ny, nx, nl, bs, na, nc, assign.cap)
+    if ws_bytes == 0:
+        raise RuntimeError("ComputeLoss: unsupported problem size (a level exceeds 2^32 elements)")
+    ws = L.workspace(ws_bytes, dev)
+    out = torch.empty(5 + nl, dtype=torch.float32, device=dev)
+    ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
+    with torch.cuda.device(dev):
+        L.check(lib.dh_yolo_loss_fwd(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
+                                     L.ptr(assign.anch), L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap,
+                                     ctypes.byref(hyp), L.ptr(out), L.ptr(ws), ws_bytes, L.stream()),
+                "dh_yolo_loss_fwd")
+    return out, ws
+
+
+def _loss_bwd(assign, hyp, nc, maps, ws, g_loss):
+    """Launch the backward kernels for upstream gradient g_loss (1 float on the device); returns grads."""
+    nl = len(maps)
+    bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
+    grads = [torch.empty_like(x) for x in maps]
+    ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
+    gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
+    with torch.cuda.device(maps[0].device):
+        L.check(L.lib().dh_yolo_loss_bwd(ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc,
+                                         L.ptr(assign.idx), L.ptr(assign.tbox), L.ptr(assign.anch),
+                                         L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap, ctypes.byref(hyp),
+                                         L.ptr(g_loss), gptrs, L.ptr(ws), ws.numel(), L.stream()), "dh_yolo_loss_bwd")
+    return grads
+
+
 class _YoloLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, assign, hyp, nc, *p):
         maps = [L.dev_f32(x, f"p[{i}]").contiguous() for i, x in enumerate(p)]
-        nl = len(maps)
-        bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
-        for x, ny, nx in zip(maps, assign.ny, assign.nx):
-            if tuple(x.shape) != (bs, na, ny, nx, nc + 5):
-                raise RuntimeError(f"ComputeLoss: level shape {tuple(x.shape)} does not match (bs,na,ny,nx,5+nc)")
-        dev = maps[0].device
-        lib = L.lib()
-        ny, nx = L.int_array(assign.ny), L.int_array(assign.nx)
-        ws_bytes = lib.dh_yolo_loss_workspace(ny, nx, nl, bs, na, nc, assign.cap)
-        if ws_bytes == 0:
-            raise RuntimeError("ComputeLoss: unsupported problem size (a level exceeds 2^32 elements)")
-        ws = L.workspace(ws_bytes, dev)
-        out = torch.empty(5 + nl, dtype=torch.float32, device=dev)
-        ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
-        with torch.cuda.device(dev):
-            L.check(lib.dh_yolo_loss_fwd(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
-                                         L.ptr(assign.anch), L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap,
-                                         ctypes.byref(hyp), L.ptr(out), L.ptr(ws), ws_bytes, L.stream()),
-                    "dh_yolo_loss_fwd")
+        out, ws = _loss_fwd(assign, hyp, nc, maps)
         ctx.save_for_backward(*maps)
-        ctx.state = (assign, hyp, nc, ws, ws_bytes, [x.dtype for x in p])
+        ctx.state = (assign, hyp, nc, ws, [x.dtype for x in p])
         loss = out[0:1].clone()
         ctx.mark_non_differentiable(out)
         return loss, out
@@ -83,18 +104,8 @@ class _YoloLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_out):
         maps = ctx.saved_tensors
-        assign, hyp, nc, ws, ws_bytes, dtypes = ctx.state
-        nl = len(maps)
-        bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
-        grads = [torch.empty_like(x) for x in maps]
-        g = g_loss.reshape(1).float().contiguous()
-        ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
-        gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
-        with torch.cuda.device(maps[0].device):
-            L.check(L.lib().dh_yolo_loss_bwd(ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc,
-                                             L.ptr(assign.idx), L.ptr(assign.tbox), L.ptr(assign.anch),
-                                             L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap, ctypes.byref(hyp),
-                                             L.ptr(g), gptrs, L.ptr(ws), ws_bytes, L.stream()), "dh_yolo_loss_bwd")
+        assign, hyp, nc, ws, dtypes = ctx.state
+        grads = _loss_bwd(assign, hyp, nc, maps, ws, g_loss.reshape(1).float().contiguous())
         return (None, None, None) + tuple(gr if dt == torch.float32 else gr.to(dt) for gr, dt in zip(grads, dtypes))
 
 
@@ -141,6 +152,26 @@ class ComputeLoss:
             self.balance = [b * 0.9999 + 0.0001 / o for b, o in zip(self.balance, obji)]
             self.balance = [x / self.balance[self.ssi] for x in self.balance]
         return loss, out[1:4].detach()
+
+    def forward_backward(self, p, targets, grad_loss=None):
+        """Loss and its gradients in one call, without the autograd engine: (loss[1], loss_items[3], [dL/dp_i]).
+
+        Same kernels as __call__ followed by backward(); grad_loss (1 float on the device, default 1) is the
+        upstream gradient of the loss.  Everything stays on the calling stream with no host synchronisation,
+        which makes the call safe to capture in a HIP graph (the autograd engine's cross-stream bookkeeping is not).
+        """
+        if self.sort_obj_iou or self.autobalance:
+            raise NotImplementedError("forward_backward supports neither sort_obj_iou nor autobalance")
+        maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
+        shapes = [(x.shape[2], x.shape[3]) for x in maps]
+        assign = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+        self.last_positive_counts = assign.counts
+        hyp = self._hyp_struct()
+        out, ws = _loss_fwd(assign, hyp, int(self.nc), maps)
+        if grad_loss is None:
+            grad_loss = torch.ones(1, dtype=torch.float32, device=maps[0].device)
+        grads = _loss_bwd(assign, hyp, int(self.nc), maps, ws, grad_loss.reshape(1).float().contiguous())
+        return out[0:1], out[1:4], grads
 
     def build_targets(self, p, targets):
         shapes = [(x.shape[2], x.shape[3]) for x in p]

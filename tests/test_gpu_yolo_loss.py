@@ -121,3 +121,46 @@ def test_compute_loss_bs8_640_vs_oracle():
     nz = (gg[0][..., :4] != 0).any(-1).sum().item()
     assert 0 < nz <= 5 * 3 * 80
     assert (gg[0][..., 4] != 0).all()
+
+
+def test_full_size_bs64_640_pipeline_vs_oracle():
+    """BASELINE configuration 2 at full size: bs 64 @ 640 px, 80 classes, 640 targets.
+    decode (1e-5), assignment (bit-exact), loss + gradients (1e-5), NMS on the oracle's decoded tensor (bit-exact)."""
+    from object_detection_amd.general import non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    from oracle import nms as onms
+    rs = np.random.RandomState(2002)
+    bs, nc = 64, 80
+    anchors = oy.grid_anchors()
+    levels = synth_head(rs, bs, 640, nc)
+    targets = synth_targets(rs, 640, bs)
+    hyp = dict(oy.HYP_SCRATCH)
+    want_fn = oy.YoloLossOracle(anchors, hyp, nc=nc)
+    # plant confident predictions on the assigned cells so that NMS has clusters to resolve
+    for l, t in enumerate(want_fn.targets_for([T(x) for x in levels], T(targets))):
+        levels[l][t["b"], t["a"], t["gj"], t["gi"], 4] = 1.5 + rs.normal(0, 1, len(t["b"]))
+        levels[l][t["b"], t["a"], t["gj"], t["gi"], 5 + t["tcls"]] = 2.0 + rs.normal(0, 1, len(t["b"]))
+        levels[l][t["b"], t["a"], t["gj"], t["gi"], 0:4] *= 0.3
+    p = [T(x).requires_grad_(True) for x in levels]
+    wl, wi = want_fn(p, T(targets))
+    wg = torch.autograd.grad(wl, p)
+    crit = make_loss(anchors, nc, hyp)
+    d = [T(x).cuda().requires_grad_(True) for x in levels]
+    gl, gi = crit(d, T(targets).cuda())
+    gg = torch.autograd.grad(gl, d)
+    close(gl, wl.detach())
+    close(gi, wi)
+    for a, b in zip(gg, wg):
+        close(a, b)
+    del gg, wg
+    wz = oy.detect_decode([T(x) for x in levels], anchors, oy.YOLOV5S_STRIDES)
+    gz = detect_decode([x.detach() for x in d], anchors.cuda(), torch.tensor(oy.YOLOV5S_STRIDES))
+    close(gz, wz)
+    # NMS is fed the oracle's decoded tensor so that the comparison is exact (stage-wise parity)
+    for kw in (dict(conf_thres=0.25, iou_thres=0.45, max_det=300), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)):
+        want = onms.non_max_suppression(wz.clone(), **kw)
+        got = non_max_suppression(wz.cuda(), **kw)
+        assert [int(g.shape[0]) for g in got] == [int(w.shape[0]) for w in want]
+        for g, w in zip(got, want):
+            assert torch.equal(g.cpu(), w)
+        assert sum(w.shape[0] for w in want) > 1000

@@ -48,6 +48,11 @@ def main():
     bench.plant_objects(levels, targets, crit)
     strides = torch.tensor([8., 16., 32.])
     A = 25200
+    if "copy" in only:
+        src = torch.empty(bs * A * 85, device=dev)
+        dst = torch.empty_like(src)
+        us = timed(lambda: dst.copy_(src), args.iters)
+        print(f"torch copy (same bytes) {us:9.1f} us  {680.0 * A * bs / us / 1e3:8.1f} GB/s")
     if "decode" in only:
         us = timed(lambda: detect_decode(levels, anchors, strides), args.iters)
         print(f"decode            {us:9.1f} us   {680.0 * A * bs / us / 1e3:8.1f} GB/s (680 B/anchor)")
