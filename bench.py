@@ -161,11 +161,11 @@ def main():
     p = [x.requires_grad_(True) for x in levels]
 
     from object_detection_amd.dist import pack_loss_stats
-    from object_detection_amd.general import nms_finish, nms_launch
+    from object_detection_amd.general import nms_launch, nms_meta_to_host, nms_views
     from object_detection_amd.graphs import GraphedStage
 
     use_graph = args.graph
-    stages = ("decode", "assign+loss_fwd+bwd", "nms", "allreduce+host")
+    stages = ("decode", "assign+loss_fwd+bwd", "nms", "allreduce+d2h")
     ev = {s: [] for s in stages}
     cap = A
 
@@ -188,7 +188,8 @@ def main():
         g_decode.replay()      # give the NMS warm-up real predictions to work on
         g_nms = GraphedStage(lambda: nms_launch(z_static, 0.25, 0.45, max_det=300, cap=cap))
 
-    def step(record):
+    def launch(record):
+        """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation."""
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if record else None
         if record: marks[0].record()
         z = g_decode.replay() if use_graph else f_decode()
@@ -199,23 +200,38 @@ def main():
         if record: marks[3].record()
         if world > 1:
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)          # [lbox, lobj, lcls, n_pos] over RCCL
-        dets, _ = nms_finish(rows, meta, cap)                    # the step's only device-to-host copy (3*bs ints)
+        host_meta, copied = nms_meta_to_host(meta)               # the step's only device-to-host copy (3*bs ints)
         if record: marks[4].record()
-        return marks, dets, loss, grads, stats
+        return dict(marks=marks, rows=rows, host_meta=host_meta, copied=copied, loss=loss, grads=grads, stats=stats)
+
+    def finish(job):
+        """Host half of a step: wait for that step's copy only, then build the per-image detection views."""
+        job["copied"].synchronize()
+        dets, _ = nms_views(job["rows"], job["host_meta"].tolist(), cap)
+        return dets
+
+    def run(n, record):
+        """n steps, software-pipelined: the host half of step i runs while the GPU works on step i+1."""
+        all_marks, prev, dets = [], None, None
+        for _ in range(n):
+            job = launch(record)
+            if prev is not None:
+                dets = finish(prev)      # prev's tensors are released here, so the allocator reuses its blocks
+            prev = job
+            all_marks.append(job["marks"])
+        if prev is not None:
+            dets = finish(prev)
+        return all_marks, dets
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    run(args.warmup, False)
     sync_all()
     t0 = time.perf_counter()
-    all_marks = []
-    for _ in range(args.steps):
-        marks, dets, loss, grads, stats = step(True)
-        all_marks.append(marks)
+    all_marks, dets = run(args.steps, True)
     sync_all()
     elapsed = time.perf_counter() - t0
     for marks in all_marks:

@@ -138,11 +138,23 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     return rows, meta, cap
 
 
-def nms_finish(rows, meta, cap):
-    """The one device-to-host copy (3*bs ints) and the per-image views.  Returns None if the candidate
-    capacity overflowed (the caller must relaunch with the returned-by-meta larger cap)."""
-    bs = meta.numel() // 3
-    host = meta.tolist()
+def nms_meta_to_host(meta, pinned=None):
+    """Start the one device-to-host copy of the NMS bookkeeping (3*bs int32) on the current stream.
+
+    Returns (host tensor in pinned memory, event recorded after the copy): a caller that wants to keep the
+    GPU busy can enqueue more work before waiting on the event (software pipelining of consecutive batches).
+    """
+    if pinned is None:
+        pinned = torch.empty(meta.numel(), dtype=torch.int32, pin_memory=True)
+    pinned.copy_(meta, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record()
+    return pinned, done
+
+
+def nms_views(rows, host, cap):
+    """Per-image (k,6) views of the packed rows from the host copy of meta; (None, needed_cap) on overflow."""
+    bs = len(host) // 3
     if max(host[2 * bs:]) > cap:
         return None, max(host[2 * bs:])
     # images are packed in completion order: one split() call makes every per-image view
@@ -153,6 +165,11 @@ def nms_finish(rows, meta, cap):
         for i, piece in zip(order, rows[:sum(count)].split([count[i] for i in order])):
             result[i] = piece
     return result, cap
+
+
+def nms_finish(rows, meta, cap):
+    """Blocking variant: copy meta to the host now and build the views."""
+    return nms_views(rows, meta.tolist(), cap)
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
