@@ -160,7 +160,6 @@ def main():
     A = sum(3 * (img // s) ** 2 for s in STRIDES)
     p = [x.requires_grad_(True) for x in levels]
 
-    from object_detection_amd.dist import pack_loss_stats
     from object_detection_amd.general import nms_launch, nms_meta_to_host, nms_views
     from object_detection_amd.graphs import GraphedStage
 
@@ -179,7 +178,7 @@ def main():
         else:
             loss, items = crit(p, targets)
             grads = torch.autograd.grad(loss, p)
-        return loss, items, grads, pack_loss_stats(items, crit.last_positive_counts)
+        return loss, items, grads, crit.last_stats       # [lbox, lobj, lcls, n_pos], written by the loss kernel
 
     if use_graph:   # one HIP graph per stage so that events between replays still bracket each stage
         g_decode = GraphedStage(f_decode)
@@ -188,26 +187,39 @@ def main():
         g_decode.replay()      # give the NMS warm-up real predictions to work on
         g_nms = GraphedStage(lambda: nms_launch(z_static, 0.25, 0.45, max_det=300, cap=cap))
 
+    host_s = {s: 0.0 for s in stages + ("finish",)}
+
     def launch(record):
         """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation."""
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if record else None
+        h0 = time.perf_counter()
         if record: marks[0].record()
         z = g_decode.replay() if use_graph else f_decode()
         if record: marks[1].record()
+        h1 = time.perf_counter()
         loss, items, grads, stats = g_loss.replay() if use_graph else f_loss()
         if record: marks[2].record()
+        h2 = time.perf_counter()
         rows, meta, _ = g_nms.replay() if use_graph else nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
         if record: marks[3].record()
+        h3 = time.perf_counter()
         if world > 1:
+            stats = stats.clone()
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)          # [lbox, lobj, lcls, n_pos] over RCCL
         host_meta, copied = nms_meta_to_host(meta)               # the step's only device-to-host copy (3*bs ints)
         if record: marks[4].record()
+        h4 = time.perf_counter()
+        if record:
+            for s, d in zip(stages, (h1 - h0, h2 - h1, h3 - h2, h4 - h3)):
+                host_s[s] += d
         return dict(marks=marks, rows=rows, host_meta=host_meta, copied=copied, loss=loss, grads=grads, stats=stats)
 
     def finish(job):
         """Host half of a step: wait for that step's copy only, then build the per-image detection views."""
         job["copied"].synchronize()
+        h0 = time.perf_counter()
         dets, _ = nms_views(job["rows"], job["host_meta"].tolist(), cap)
+        host_s["finish"] += time.perf_counter() - h0
         return dets
 
     def run(n, record):
@@ -267,6 +279,7 @@ def main():
                        "global_batch": bs * world, "parallelism": f"image-sharded x{world}",
                        "planted_positive_rows": n_planted, "detections_last_step": int(sum(d.shape[0] for d in dets))},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "host_enqueue_ms": {k: round(v / args.steps * 1e3, 4) for k, v in host_s.items()},
             "launch_mode": "hip-graph per stage" if use_graph else "eager",
             "roofline": roofline,
         }

@@ -62,9 +62,11 @@ int dh_centernet_box_loss_bwd(const float* pred_xy, int64_t pred_xy_bstride, con
 /* Detect.forward inference decode of all levels into (bs, sum na*ny*nx, no)
  * (object_detection/yolov5/models/yolo.py:56-70,72-81).  level_ptrs/ny/nx/strides are host
  * arrays of nl entries; anchor_px is host (nl,na,2) = anchors[l]*stride[l] as _make_grid forms it;
- * level l input is (bs,na,ny,nx,no) contiguous on the device. */
+ * level l input is (bs,na,ny,nx,no) contiguous on the device.  obj_plane (optional, may be NULL):
+ * (bs, A) floats that receive a compact copy of the decoded objectness column out[:, :, 4], which
+ * dh_nms_batched can read instead of the 340-byte-strided column. */
 int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
-                   const float* anchor_px, const float* strides, float* out, void* stream);
+                   const float* anchor_px, const float* strides, float* out, float* obj_plane, void* stream);
 
 /* Batched non_max_suppression (object_detection/yolov5/utils/general.py:647-738) over
  * pred (bs, A, 5+nc) = [x,y,w,h,obj,cls...].  Output rows are [x1,y1,x2,y2,conf,cls] in the
@@ -75,12 +77,14 @@ int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx,
  * candidate capacity overflowed and the call must be repeated with a larger cap (only possible with
  * multi_label; cap = A always suffices otherwise).
  * class_keep: nc bytes on the device (1 = keep class) or NULL (general.py:705-706).
+ * obj_plane: NULL, or (bs, A) floats holding exactly pred[:, :, 4] (see dh_yolo_decode).
  * max_nms = 30000 and max_wh = 7680 in the reference (general.py:663-664).  All of out, out_span,
  * cand_count, workspace are device memory; workspace must be 256-byte aligned. */
 size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms);
-int dh_nms_batched(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres, int multi_label,
-                   int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
-                   float* out, int* out_span, int* cand_count, void* workspace, size_t workspace_bytes, void* stream);
+int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
+                   int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
+                   double max_wh, int cap, float* out, int* out_span, int* cand_count, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* torchvision.ops.nms(boxes[n,4] xyxy, scores[n], iou_threshold) as called at
  * object_detection/yolov5/utils/general.py:722 and object_detection/detectors/centernet/dataset.py:263:
@@ -120,9 +124,9 @@ typedef struct dh_yolo_hyp {
 
 /* ComputeLoss.__call__ (loss.py:117-167) given the assignment produced by dh_build_targets.
  * p / grad_p: host arrays of nl device pointers to (bs,na,ny,nx,5+nc) maps.
- * out (device, 5+nl floats): [0] loss, [1..3] lbox, lobj, lcls after gains, [4..4+nl) mean objectness
- * BCE per level (what autobalance reads, loss.py:158), [4+nl] rows ignored because their image/anchor
- * index was outside the maps.  The forward leaves in `workspace` what the backward needs (per-row IoU and
+ * out (device, 6+nl floats): [0] loss, [1..3] lbox, lobj, lcls after gains, [4] assigned rows over all
+ * levels, [5..5+nl) mean objectness BCE per level (what autobalance reads, loss.py:158), [5+nl] rows
+ * ignored because their image/anchor index was outside the maps.  The forward leaves in `workspace` what the backward needs (per-row IoU and
  * the cell-owner map), so the same workspace must be passed to dh_yolo_loss_bwd unmodified.
  * The backward writes every element of every grad_p[l] (no pre-zeroing needed); grad_loss is the
  * upstream gradient of out[0] (1 float, device). */

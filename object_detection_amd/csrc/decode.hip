@@ -16,6 +16,7 @@ namespace {
 struct decode_level {
     const float* src;     // (bs, na, ny, nx, no) contiguous
     uint32_t first;       // first output element of this level inside one image's span
+    uint32_t row_first;   // first output row (anchor) of this level inside one image
     uint32_t elems;       // na*ny*nx*no
     dh_fastdiv plane;     // ny*nx
     dh_fastdiv nx;
@@ -29,6 +30,8 @@ struct decode_params {
     int nl;
     dh_fastdiv no;
     uint32_t per_image;   // elements of one image's output span = A*no
+    uint32_t rows_per_image;
+    float* obj_plane;     // optional (bs, A) copy of the objectness column, or nullptr
 };
 
 // box channels (c < 4) of row `row`: xy = (2s - 0.5 + grid) * stride, wh = (2s)^2 * anchor_px
@@ -92,6 +95,15 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
                     if (c < 4) y[k] = decode_box(L, r, c, y[k]);
                 }
             }
+            if (P.obj_plane) {       // channel 4 of `row` sits at offset 4 - c0, of `row + 1` at 4 - c0 + no
+                int k4 = 4 - (int)c0;
+                uint32_t r4 = row;
+                if (k4 < 0) { k4 += (int)no; r4 = row + 1; }
+                if (k4 < 4) {
+                    const float ov = k4 == 0 ? y[0] : (k4 == 1 ? y[1] : (k4 == 2 ? y[2] : y[3]));
+                    P.obj_plane[(size_t)b * P.rows_per_image + L.row_first + r4] = ov;
+                }
+            }
             const dh_f4 o = {y[0], y[1], y[2], y[3]};
             if (NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<dh_f4*>(dst + (size_t)e));
             else *reinterpret_cast<dh_f4*>(dst + (size_t)e) = o;
@@ -105,6 +117,7 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
             const uint32_t row = dh_div(v, P.no);
             const uint32_t c = v - row * no;
             if (c < 4) y = decode_box(L, row, c, y);
+            if (c == 4 && P.obj_plane) P.obj_plane[(size_t)b * P.rows_per_image + L.row_first + row] = y;
             dst[v] = y;
         }
     }
@@ -113,7 +126,8 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
 }  // namespace
 
 extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
-                              int no, const float* anchor_px, const float* strides, float* out, void* stream)
+                              int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
+                              void* stream)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 5 || bs < 0 || bs > 65535) return DH_ERR_ARG;
     if (!level_ptrs || !ny || !nx || !anchor_px || !strides || (bs > 0 && !out)) return DH_ERR_ARG;
@@ -122,6 +136,7 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
     P.nl = nl;
     P.no = dh_make_fastdiv((uint32_t)no);
     uint64_t first = 0;
+    uint32_t row_first = 0;
     bool vec4 = dh_aligned16(out);
     for (int l = 0; l < nl; ++l) {
         if (!level_ptrs[l] || ny[l] < 1 || nx[l] < 1) return DH_ERR_ARG;
@@ -130,6 +145,8 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
         decode_level& L = P.lvl[l];
         L.src = level_ptrs[l];
         L.first = (uint32_t)first;
+        L.row_first = row_first;
+        row_first += (uint32_t)(na * ny[l] * nx[l]);
         L.elems = (uint32_t)elems;
         L.plane = dh_make_fastdiv((uint32_t)(ny[l] * nx[l]));
         L.nx = dh_make_fastdiv((uint32_t)nx[l]);
@@ -139,6 +156,8 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
         first += elems;
     }
     P.per_image = (uint32_t)first;
+    P.rows_per_image = row_first;
+    P.obj_plane = obj_plane;
     const int vec = vec4 ? 4 : 1;
     static int unroll = 0, nt = 0;
     if (unroll == 0) {   // tuning knobs (defaults are the measured best)

@@ -75,7 +75,8 @@ __device__ __forceinline__ row_best wave_argmax_first(float v, int c)
 // (nc <= 64*NCH), which keeps 4*NCH independent loads in flight per wave; NCH = 0 handles any nc
 // chunk by chunk.
 template <bool MULTI, int NCH>
-__global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__ pred, int A, int nc, float conf,
+__global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__ pred, const float* __restrict__ obj_plane,
+                                                       int A, int nc, float conf,
                                                        const unsigned char* __restrict__ class_keep, int cap,
                                                        u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
 {
@@ -89,7 +90,8 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__
 
     for (int row0 = (blockIdx.x * 4 + wave) * 64; row0 < A; row0 += gridDim.x * 256) {
         const int row = row0 + lane;
-        const float obj = (row < A) ? img[(size_t)row * no + 4] : 0.0f;
+        float obj = 0.0f;
+        if (row < A) obj = obj_plane ? obj_plane[(size_t)b * A + row] : img[(size_t)row * no + 4];
         const bool cand = (row < A) && (obj > conf);                       // general.py:656,675
         u64 todo = __ballot(cand);
         float my_best = 0.0f;
@@ -323,15 +325,21 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ ke
 }
 
 // ------------------------------------------------------------------------------------------ 3 gather
-__device__ __forceinline__ int float_order(float f)   // monotone float -> int for atomicMin/Max
+// monotone float <-> uint32 (ascending); both range words below are kept with atomicMax so that an
+// all-zero workspace is their valid initial state: hi_key = max key(hi), lo_inv = max ~key(lo)
+__device__ __forceinline__ uint32_t float_ukey(float f)
 {
-    const int i = __float_as_int(f);
-    return i >= 0 ? i : (i ^ 0x7fffffff);
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__device__ __forceinline__ float order_float(int i) { return __int_as_float(i >= 0 ? i : (i ^ 0x7fffffff)); }
+__device__ __forceinline__ float ukey_float(uint32_t e)
+{
+    return __uint_as_float((e & 0x80000000u) ? (e ^ 0x80000000u) : ~e);
+}
 
 struct img_range {   // per image: coordinate range of the boxes that reach NMS (+ a not-finite flag)
-    int lo, hi, bad, pad;
+    uint32_t hi_key, lo_inv;
+    int bad, pad;
 };
 
 __global__ void __launch_bounds__(256) k_nms_gather(const float* __restrict__ pred, int A, dh_fastdiv ncd,
@@ -381,10 +389,11 @@ __global__ void __launch_bounds__(256) k_nms_gather(const float* __restrict__ pr
         // The current range is read from L2 (agent scope; a CU's L1 would keep returning the initial
         // value) and the atomic is issued only if this block widens it, which is rare after the first few.
         if (lo <= hi) {
-            if (float_order(lo) < __hip_atomic_load(&range[b].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMin(&range[b].lo, float_order(lo));
-            if (float_order(hi) > __hip_atomic_load(&range[b].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(&range[b].hi, float_order(hi));
+            const uint32_t lk = ~float_ukey(lo), hk = float_ukey(hi);
+            if (lk > __hip_atomic_load(&range[b].lo_inv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&range[b].lo_inv, lk);
+            if (hk > __hip_atomic_load(&range[b].hi_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&range[b].hi_key, hk);
         }
         if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) atomicOr(&range[b].bad, 1);
     }
@@ -428,7 +437,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
     bool whole = agnostic != 0;
     if (!whole) {
         const img_range rg = range[b];
-        const float lo = order_float(rg.lo), hi = order_float(rg.hi);
+        const float lo = ukey_float(~rg.lo_inv), hi = ukey_float(rg.hi_key);
         whole = rg.bad != 0 || !(hi - lo < max_wh - 1.0f);
     }
     int s, e;
@@ -532,10 +541,11 @@ __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ 
                                                       const int* __restrict__ counts, int cap, int max_nms, int max_det,
                                                       float* __restrict__ out, long long* __restrict__ out_index,
                                                       int* __restrict__ out_count, int* __restrict__ cursor,
-                                                      int2* __restrict__ out_span)
+                                                      int2* __restrict__ out_span, int* __restrict__ cand_count)
 {
     const int b = blockIdx.x;
     int n = counts[b];
+    if (cand_count && threadIdx.x == 0) cand_count[b] = n;
     if (n > cap) n = cap;
     const int m = n < max_nms ? n : max_nms;
     __shared__ int wcount[16];
@@ -613,7 +623,7 @@ __global__ void __launch_bounds__(256) k_nms_plain_gather(const float* __restric
 struct nms_layout {
     int cap_pad, m_cap, m_pad;
     size_t off_counts, off_range, off_cursor, off_seg, off_keys, off_keys2, off_det, off_keep, off_spill, total;
-    size_t zero_bytes;   // [off_seg, off_seg + zero_bytes) = segment table + keep flags, cleared by one memset
+    size_t zero_bytes;   // [0, zero_bytes) = counts, ranges, cursor, segment table, keep flags: cleared by one memset
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -638,26 +648,13 @@ nms_layout make_layout(int bs, int cap, int max_nms, int nc)
     L.off_cursor = o; o = align_up(o + sizeof(int), 256);
     L.off_seg = o; o = align_up(o + sizeof(int2) * (size_t)bs * nc, 256);
     L.off_keep = o; o = align_up(o + (size_t)bs * L.m_cap, 256);
-    L.zero_bytes = o - L.off_seg;
+    L.zero_bytes = o;
     L.off_keys = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.cap_pad, 256);
     L.off_keys2 = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.m_pad, 256);
     L.off_det = o; o = align_up(o + sizeof(float) * 6 * (size_t)bs * L.m_cap, 256);
     L.off_spill = o; o = align_up(o + sizeof(float4) * (size_t)bs * L.m_cap, 256);
     L.total = o;
     return L;
-}
-
-__global__ void k_nms_init(int* counts, img_range* range, int* cursor, int bs)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *cursor = 0;
-    if (i < bs) {
-        counts[i] = 0;
-        range[i].lo = 0x7fffffff;       // above every float_order()
-        range[i].hi = (int)0x80000000;
-        range[i].bad = 0;
-        range[i].pad = 0;
-    }
 }
 
 float round_down_to_float(double t)
@@ -675,7 +672,7 @@ extern "C" size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms)
     return make_layout(bs, cap, max_nms, nc).total;
 }
 
-extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres,
+extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
                               int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
                               int max_nms, double max_wh, int cap, float* out, int* out_span, int* cand_count,
                               void* workspace, size_t workspace_bytes, void* stream)
@@ -701,12 +698,11 @@ extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double c
     const float thr = round_down_to_float(iou_thres);
 
     int* cursor = (int*)(ws + L.off_cursor);
-    hipLaunchKernelGGL(k_nms_init, dim3((bs + 255) / 256), dim3(256), 0, st, counts, range, cursor, bs);
-    if (hipMemsetAsync(ws + L.off_seg, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (hipMemsetAsync(ws, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;   // every counter's initial state is 0
     int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks
     const int gx_cap = 8192 / bs > 1 ? 8192 / bs : 1;
     if (gx > gx_cap) gx = gx_cap;
-#define DH_PREFILTER(M, N) hipLaunchKernelGGL((k_nms_prefilter<M, N>), dim3(gx, bs), dim3(256), 0, st, pred, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
+#define DH_PREFILTER(M, N) hipLaunchKernelGGL((k_nms_prefilter<M, N>), dim3(gx, bs), dim3(256), 0, st, pred, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
     if (multi_label) {
         if (nc <= 64) DH_PREFILTER(true, 1); else if (nc <= 128) DH_PREFILTER(true, 2); else DH_PREFILTER(true, 0);
     } else {
@@ -726,8 +722,7 @@ extern "C" int dh_nms_batched(const float* pred, int bs, int A, int nc, double c
                            max_nms, range, seg, 1, (float)max_wh, thr, max_det, keep, spill);
     }
     hipLaunchKernelGGL(k_nms_collect, dim3(bs), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, cap, max_nms,
-                       max_det, out, (long long*)nullptr, (int*)nullptr, cursor, (int2*)out_span);
-    if (hipMemcpyAsync(cand_count, counts, sizeof(int) * bs, hipMemcpyDeviceToDevice, st) != hipSuccess) return DH_ERR_LAUNCH;
+                       max_det, out, (long long*)nullptr, (int*)nullptr, cursor, (int2*)out_span, cand_count);
     return dh_launch_status();
 }
 
@@ -756,13 +751,13 @@ extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, 
     u64* keys2 = (u64*)(ws + L.off_keys2);
     float* det = (float*)(ws + L.off_det);
     float4* spill = (float4*)(ws + L.off_spill);
-    if (hipMemsetAsync(keep, 0, (size_t)L.m_cap, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (hipMemsetAsync(ws, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
     hipLaunchKernelGGL(k_nms_plain_keys, dim3((ni + 255) / 256), dim3(256), 0, st, scores, ni, keys, counts);
     hipLaunchKernelGGL(k_sort_keys, dim3(1), dim3(SORT_THREADS), 0, st, keys, counts, ni, L.cap_pad, (int2*)nullptr, 0);
     hipLaunchKernelGGL(k_nms_plain_gather, dim3((ni + 255) / 256), dim3(256), 0, st, boxes, keys, ni, det);
     hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, 1), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, counts, ni, ni, range,
                        (const int2*)nullptr, 1, 0.0f, round_down_to_float(iou_thres), ni, keep, spill);
     hipLaunchKernelGGL(k_nms_collect, dim3(1), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, ni, ni, ni,
-                       (float*)nullptr, (long long*)keep_index, keep_count, (int*)nullptr, (int2*)nullptr);
+                       (float*)nullptr, (long long*)keep_index, keep_count, (int*)nullptr, (int2*)nullptr, (int*)nullptr);
     return dh_launch_status();
 }

@@ -10,8 +10,9 @@
 // Forward = 3 launches: positives (one wave per assigned row), dense objectness (reads the strided
 // obj logit of every anchor + a 4-byte owner word), finalisation.  The dense tobj tensor is never
 // built: a per-cell owner map (last assigned row, by atomicMax of the row id) stands in for it.
-// Backward = 2 launches: one streaming pass writes the whole dense gradient (zeros + obj term,
-// 16-byte stores), then the positive rows add their box / class terms.
+// The objectness pass also stores d BCE / d logit per anchor (4 B each), so the backward never re-reads
+// the strided logits.  Backward = 2 launches: one streaming pass writes the whole dense gradient (zeros +
+// scaled objectness term, 16-byte stores), then the positive rows add their box / class terms.
 #include "dh_iou.h"
 #include "../../include/dethead.h"
 
@@ -147,7 +148,8 @@ __device__ __forceinline__ float tobj_of(const yl_params& P, int own, const floa
 #define OBJ_CELLS_PER_BLOCK 1024
 
 __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int* __restrict__ owner,
-                                                    const float* __restrict__ iou_ws, double* __restrict__ partial)
+                                                    const float* __restrict__ iou_ws, double* __restrict__ partial,
+                                                    float* __restrict__ dobj)
 {
     unsigned blk = blockIdx.x;
     const int l = level_of_block(P, blk);
@@ -160,7 +162,11 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
         const long cell = (long)blk * OBJ_CELLS_PER_BLOCK + u * 256 + threadIdx.x;
         if (cell < L.cells) {
             const float x = L.p[(size_t)cell * P.no + 4];
-            acc += (double)bce_value(x, tobj_of(P, own_l[cell], iou_l), P.obj_pw, P.gamma);       // loss.py:155
+            const float t = tobj_of(P, own_l[cell], iou_l);
+            acc += (double)bce_value(x, t, P.obj_pw, P.gamma);                                     // loss.py:155
+            // the backward needs d BCE / d logit of every anchor: keep it compact (4 B per anchor) so that
+            // the gradient pass does not have to touch the 340-byte-strided logits again
+            dobj[L.cell_first + cell] = bce_grad(x, t, P.obj_pw, P.gamma);
         }
     }
     __shared__ double red[4];
@@ -170,7 +176,8 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// out: [0] loss, [1..3] lbox,lobj,lcls (after gains), [4..4+nl) mean objectness BCE per level, [4+nl] ignored rows
+// out: [0] loss, [1..3] lbox,lobj,lcls (after gains), [4] assigned rows over all levels,
+//      [5..5+nl) mean objectness BCE per level, [5+nl] ignored rows
 #define FINAL_THREADS 1024
 
 __global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, const int* __restrict__ counts,
@@ -196,7 +203,9 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, c
     __syncthreads();
     if (threadIdx.x == 0) {
         float lbox = 0.0f, lobj = 0.0f, lcls = 0.0f;
+        long n_pos = 0;
         for (int l = 0; l < P.nl; ++l) {
+            n_pos += counts[l];
             double tb = 0.0, tc = 0.0, to = 0.0;
             for (int w = 0; w < FINAL_THREADS / 64; ++w) { tb += red[3 * l][w]; tc += red[3 * l + 1][w]; to += red[3 * l + 2][w]; }
             const int n = counts[l];
@@ -206,12 +215,13 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, c
             lbox += s_box;
             lcls += s_cls;
             lobj += s_obj * P.lvl[l].balance;                                                    // loss.py:156
-            out[4 + l] = s_obj;
+            out[5 + l] = s_obj;
         }
         lbox *= P.box; lobj *= P.obj; lcls *= P.cls;                                             // loss.py:162-164
         out[0] = (lbox + lobj + lcls) * (float)P.bs;
         out[1] = lbox; out[2] = lobj; out[3] = lcls;
-        out[4 + P.nl] = (float)invalid[0];
+        out[4] = (float)n_pos;
+        out[5 + P.nl] = (float)(invalid[0] + 1);
     }
 }
 
@@ -220,15 +230,13 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, c
 #define GRAD_VEC_PER_BLOCK 1024
 
 template <int VEC>
-__global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const int* __restrict__ owner,
-                                                    const float* __restrict__ iou_ws, const float* __restrict__ g_loss,
-                                                    const dh_fastdiv nod)
+__global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const float* __restrict__ dobj,
+                                                    const float* __restrict__ g_loss, const dh_fastdiv nod)
 {
     unsigned blk = blockIdx.x;
     const int l = level_of_block(P, blk);
     const yl_level& L = P.lvl[l];
-    const float* __restrict__ iou_l = iou_ws + (size_t)l * P.cap;
-    const int* __restrict__ own_l = owner + L.cell_first;
+    const float* __restrict__ d_l = dobj + L.cell_first;
     const float scale = g_loss[0] * (float)P.bs * P.obj * L.balance / (float)L.cells;
     const size_t total = (size_t)L.cells * P.no;
     const size_t nvec = total / VEC;
@@ -248,8 +256,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const int
         uint32_t hit = cell;
         if (k4 < 0) { k4 += (int)nod.d; hit = cell + 1; }
         if (k4 < VEC && hit < (uint32_t)L.cells) {
-            const float x = L.p[(size_t)hit * P.no + 4];
-            const float g = scale * bce_grad(x, tobj_of(P, own_l[hit], iou_l), P.obj_pw, P.gamma);
+            const float g = scale * d_l[hit];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) if (k == k4) o[k] = g;
         }
@@ -301,7 +308,7 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
 }
 
 struct yl_ws {
-    size_t off_owner, off_iou, off_cls, off_partial, off_invalid, total;
+    size_t off_owner, off_iou, off_cls, off_partial, off_invalid, off_dobj, total;
     long cells_total;
     unsigned obj_blocks;
 };
@@ -345,11 +352,12 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
     for (int l = 0; l < nl; ++l) fwd_blocks += (unsigned)((P.lvl[l].cells + OBJ_CELLS_PER_BLOCK - 1) / OBJ_CELLS_PER_BLOCK);
     W.obj_blocks = fwd_blocks;
     size_t o = 0;
-    W.off_owner = o; o = up256(o + sizeof(int) * (size_t)first);
+    W.off_owner = o; o = up256(o + sizeof(int) * ((size_t)first + 1));   // + the ignored-row counter, cleared by the same fill
     W.off_iou = o; o = up256(o + sizeof(float) * (size_t)nl * (cap > 0 ? cap : 1));
     W.off_cls = o; o = up256(o + sizeof(float) * (size_t)nl * (cap > 0 ? cap : 1));
     W.off_partial = o; o = up256(o + sizeof(double) * fwd_blocks);
-    W.off_invalid = o; o = up256(o + sizeof(int));
+    W.off_dobj = o; o = up256(o + sizeof(float) * (size_t)first);
+    W.off_invalid = W.off_owner + sizeof(int) * (size_t)first;
     W.total = o;
     (void)blocks;
     return true;
@@ -392,12 +400,13 @@ extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int*
     double* partial = (double*)(ws + W.off_partial);
     int* invalid = (int*)(ws + W.off_invalid);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(owner, 0xFF, sizeof(int) * (size_t)W.cells_total, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (hipMemsetAsync(invalid, 0, sizeof(int), st) != hipSuccess) return DH_ERR_LAUNCH;
+    // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
+    if (hipMemsetAsync(owner, 0xFF, sizeof(int) * ((size_t)W.cells_total + 1), st) != hipSuccess) return DH_ERR_LAUNCH;
     if (cap > 0)
         hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
                            anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
-    hipLaunchKernelGGL(k_yl_obj_fwd, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial);
+    hipLaunchKernelGGL(k_yl_obj_fwd, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
+                       (float*)(ws + W.off_dobj));
     hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(FINAL_THREADS), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
     return dh_launch_status();
 }
@@ -425,12 +434,11 @@ extern "C" int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int*
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
     const char* ws = (const char*)workspace;
-    const int* owner = (const int*)(ws + W.off_owner);
-    const float* iou_ws = (const float*)(ws + W.off_iou);
+    const float* dobj = (const float*)(ws + W.off_dobj);
     hipStream_t st = (hipStream_t)stream;
     const dh_fastdiv nod = dh_make_fastdiv((uint32_t)P.no);
-    if (vec4) hipLaunchKernelGGL(k_yl_obj_bwd<4>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, grad_loss, nod);
-    else hipLaunchKernelGGL(k_yl_obj_bwd<1>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, grad_loss, nod);
+    if (vec4) hipLaunchKernelGGL(k_yl_obj_bwd<4>, dim3(sum_blocks(P)), dim3(256), 0, st, P, dobj, grad_loss, nod);
+    else hipLaunchKernelGGL(k_yl_obj_bwd<1>, dim3(sum_blocks(P)), dim3(256), 0, st, P, dobj, grad_loss, nod);
     if (cap > 0)
         hipLaunchKernelGGL(k_yl_pos_bwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
                            anch, (const long long*)tcls, counts, grad_loss);

@@ -17,13 +17,15 @@ def pack_loss_stats(loss_items, positive_counts):
     return torch.cat((loss_items.detach().reshape(3).float(), n_pos.to(loss_items.device)))
 
 
-def all_reduce_loss_stats(loss_items, positive_counts, group=None):
+def all_reduce_loss_stats(loss_items, positive_counts=None, group=None):
     """Global means of (lbox, lobj, lcls) and the global number of assigned positives.
 
+    loss_items: the 3 loss terms with positive_counts (per-level rows), or the ready-made 4-element
+    [lbox, lobj, lcls, n_pos] that ComputeLoss leaves in `.last_stats` (then positive_counts is None).
     Returns a 4-element tensor [mean lbox, mean lobj, mean lcls, sum n_pos]; with no initialised
     process group (single process) the local values are returned unchanged.
     """
-    stats = pack_loss_stats(loss_items, positive_counts)
+    stats = loss_items.detach().clone() if positive_counts is None else pack_loss_stats(loss_items, positive_counts)
     if not (dist.is_available() and dist.is_initialized()):
         return stats
     world = dist.get_world_size(group)

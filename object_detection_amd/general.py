@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from .yolo import objectness_plane
 
 MAX_WH = 7680      # general.py:663
 MAX_NMS = 30000    # general.py:664
@@ -110,8 +111,11 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     bs, _, no = pred.shape
     nc = no - 5
     multi_label = bool(multi_label) and nc > 1                                      # general.py:667
+    plane = None
     if labels and len(labels):
         pred = _with_apriori_labels(pred, labels, nc)
+    elif pred is prediction:
+        plane = objectness_plane(prediction)          # compact obj column left behind by detect_decode, if still valid
     A = pred.shape[1]
     dev = pred.device
     max_det = int(max_det)
@@ -131,7 +135,7 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
     with torch.cuda.device(dev):
-        L.check(lib.dh_nms_batched(L.ptr(pred), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
+        L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
                                    int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap,
                                    L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs), L.ptr(ws),
                                    ws_bytes, L.stream()), "dh_nms_batched")

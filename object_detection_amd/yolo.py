@@ -1,4 +1,6 @@
 """Drop-in for the YOLOv5 Detect head (object_detection/yolov5/models/yolo.py:33-81)."""
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -6,6 +8,22 @@ from . import _lib as L
 
 
 _ANCHOR_CACHE = {}
+_OBJ_PLANES = {}    # data_ptr of a decoded tensor -> (weakref to it, its version counter, compact objectness (bs, A))
+
+
+def objectness_plane(pred):
+    """The compact copy of pred[:, :, 4] written by detect_decode for exactly this tensor, or None.
+
+    It is only returned while `pred` is the very tensor detect_decode produced and has not been written to
+    since (same storage, shape and version counter), so consumers may read it instead of the strided column.
+    """
+    hit = _OBJ_PLANES.get(pred.data_ptr())
+    if hit is None:
+        return None
+    ref, version, plane = hit
+    if ref() is pred and pred._version == version and plane.shape == pred.shape[:2]:
+        return plane
+    return None
 
 
 def _anchor_pixels(anchors, stride):
@@ -40,10 +58,17 @@ def detect_decode(levels, anchors, stride):
     total = sum(na * a * b for a, b in zip(ny, nx))
     anchor_px, strides = _anchor_pixels(anchors, stride)
     out = torch.empty((bs, total, no), dtype=torch.float32, device=xs[0].device)
+    plane = torch.empty((bs, total), dtype=torch.float32, device=xs[0].device)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
     with torch.cuda.device(out.device):
         L.check(L.lib().dh_yolo_decode(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
-                                       L.ptr(out), L.stream()), "dh_yolo_decode")
+                                       L.ptr(out), L.ptr(plane), L.stream()), "dh_yolo_decode")
+    if len(_OBJ_PLANES) > 8:
+        for k in [k for k, v in _OBJ_PLANES.items() if v[0]() is None]:
+            del _OBJ_PLANES[k]
+        if len(_OBJ_PLANES) > 8:
+            _OBJ_PLANES.clear()
+    _OBJ_PLANES[out.data_ptr()] = (weakref.ref(out), out._version, plane)
     return out
 
 

@@ -65,7 +65,7 @@ def _loss_fwd(assign, hyp, nc, maps):
     if ws_bytes == 0:
         raise RuntimeError("ComputeLoss: unsupported problem size (a level exceeds 2^32 elements)")
     ws = L.workspace(ws_bytes, dev)
-    out = torch.empty(5 + nl, dtype=torch.float32, device=dev)
+    out = torch.empty(6 + nl, dtype=torch.float32, device=dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     with torch.cuda.device(dev):
         L.check(lib.dh_yolo_loss_fwd(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
@@ -97,9 +97,9 @@ class _YoloLoss(torch.autograd.Function):
         out, ws = _loss_fwd(assign, hyp, nc, maps)
         ctx.save_for_backward(*maps)
         ctx.state = (assign, hyp, nc, ws, [x.dtype for x in p])
-        loss = out[0:1].clone()
-        ctx.mark_non_differentiable(out)
-        return loss, out
+        loss, rest = out[0:1], out[1:]      # [lbox, lobj, lcls, n_pos, obji per level..., ignored rows]
+        ctx.mark_non_differentiable(rest)
+        return loss, rest
 
     @staticmethod
     def backward(ctx, g_loss, _g_out):
@@ -121,6 +121,7 @@ class ComputeLoss:
     def __init__(self, model, autobalance=False):
         self.sort_obj_iou = False
         self.last_positive_counts = None
+        self.last_stats = None
         h = model.hyp
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
         det = model.module.model[-1] if is_parallel(model) else model.model[-1]
@@ -146,12 +147,13 @@ class ComputeLoss:
         shapes = [(x.shape[2], x.shape[3]) for x in p]
         assign = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
         self.last_positive_counts = assign.counts            # (nl,) int32 on the device: rows assigned per level
-        loss, out = _YoloLoss.apply(assign, self._hyp_struct(), int(self.nc), *p)
+        loss, rest = _YoloLoss.apply(assign, self._hyp_struct(), int(self.nc), *p)
+        self.last_stats = rest[0:4]                                             # [lbox, lobj, lcls, n_pos] on the device
         if self.autobalance:                                                    # loss.py:157-161 (host round trip)
-            obji = out[4:4 + self.nl].tolist()
+            obji = rest[4:4 + self.nl].tolist()
             self.balance = [b * 0.9999 + 0.0001 / o for b, o in zip(self.balance, obji)]
             self.balance = [x / self.balance[self.ssi] for x in self.balance]
-        return loss, out[1:4].detach()
+        return loss, rest[0:3]
 
     def forward_backward(self, p, targets, grad_loss=None):
         """Loss and its gradients in one call, without the autograd engine: (loss[1], loss_items[3], [dL/dp_i]).
@@ -171,6 +173,7 @@ class ComputeLoss:
         if grad_loss is None:
             grad_loss = torch.ones(1, dtype=torch.float32, device=maps[0].device)
         grads = _loss_bwd(assign, hyp, int(self.nc), maps, ws, grad_loss.reshape(1).float().contiguous())
+        self.last_stats = out[1:5]
         return out[0:1], out[1:4], grads
 
     def build_targets(self, p, targets):
