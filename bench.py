@@ -137,16 +137,27 @@ def main():
                     help="EXPERIMENTAL: replay one captured HIP graph per stage instead of launching from Python")
     args = ap.parse_args()
 
+    if os.environ.get("DH_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DH_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
+    # rehearsal knobs for a one-GPU box: all ranks on one device and a host-side backend
+    # (RCCL refuses two ranks on the same GPU); never set by the real multi-GPU launch
+    if os.environ.get("DH_BENCH_SHARE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("DH_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     from object_detection_amd.yolo import detect_decode
     from object_detection_amd.yolo_loss import ComputeLoss
@@ -204,7 +215,7 @@ def main():
         if record: marks[3].record()
         h3 = time.perf_counter()
         if world > 1:
-            stats = stats.clone()
+            stats = stats.clone() if backend == "nccl" else stats.cpu()   # (host tensor only in the gloo rehearsal)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)          # [lbox, lobj, lcls, n_pos] over RCCL
         host_meta, copied = nms_meta_to_host(meta)               # the step's only device-to-host copy (3*bs ints)
         if record: marks[4].record()
@@ -250,7 +261,7 @@ def main():
         for i, s in enumerate(stages):
             ev[s].append(marks[i].elapsed_time(marks[i + 1]))
     if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
