@@ -82,7 +82,7 @@ def plant_objects(levels, targets, crit):
     return sum(int(i[0].numel()) for i in indices)
 
 
-def cpu_baseline(seconds_budget=20.0):
+def cpu_baseline(seconds_budget=12.0):
     """The CPU oracle (restatement of the reference's PyTorch path) on a bounded sample: bs 8 of the same workload."""
     from oracle import nms as onms
     from oracle import yolo as oy
@@ -109,7 +109,7 @@ def cpu_baseline(seconds_budget=20.0):
     step()
     t0 = time.perf_counter()
     reps = 0
-    while reps < 3 or (time.perf_counter() - t0 < seconds_budget and reps < 50):
+    while reps < 3 or (time.perf_counter() - t0 < seconds_budget and reps < 2000):
         step()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
