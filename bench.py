@@ -133,6 +133,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2, 3),
+                    help="1: everything on one stream; 2: the NMS chain on a second stream; 3: NMS chain and loss on their own streams")
+    ap.add_argument("--autograd", action="store_true",
+                    help="call loss = crit(p, t); autograd.grad(loss, p) instead of crit.forward_backward(p, t): same kernels, "
+                         "plus the autograd engine's hop to its device thread and back (two thread wake-ups per step)")
     ap.add_argument("--graph", action="store_true",
                     help="EXPERIMENTAL: replay one captured HIP graph per stage instead of launching from Python")
     args = ap.parse_args()
@@ -170,12 +175,13 @@ def main():
     strides = torch.tensor([float(s) for s in STRIDES])
     A = sum(3 * (img // s) ** 2 for s in STRIDES)
     p = [x.requires_grad_(True) for x in levels]
+    level_shapes = [(int(x.shape[2]), int(x.shape[3])) for x in levels]
 
     from object_detection_amd.general import nms_launch, nms_meta_to_host, nms_views
     from object_detection_amd.graphs import GraphedStage
 
     use_graph = args.graph
-    stages = ("decode", "assign+loss_fwd+bwd", "nms", "allreduce+d2h")
+    stages = ("decode", "assign+loss_fwd+bwd+allreduce", "nms", "d2h")
     ev = {s: [] for s in stages}
     cap = A
 
@@ -183,11 +189,11 @@ def main():
         with torch.no_grad():
             return detect_decode(levels, anchors, strides)
 
-    def f_loss():
-        if use_graph:      # same kernels, called without the autograd engine (which cannot be captured reliably)
-            loss, items, grads = crit.forward_backward(p, targets)
+    def f_loss(assignment=None):
+        if not args.autograd:      # the fused forward+backward entry: same kernels, no autograd-engine thread hop
+            loss, items, grads = crit.forward_backward(p, targets, assignment=assignment)
         else:
-            loss, items = crit(p, targets)
+            loss, items = crit(p, targets, assignment=assignment)
             grads = torch.autograd.grad(loss, p)
         return loss, items, grads, crit.last_stats       # [lbox, lobj, lcls, n_pos], written by the loss kernel
 
@@ -199,31 +205,66 @@ def main():
         g_nms = GraphedStage(lambda: nms_launch(z_static, 0.25, 0.45, max_det=300, cap=cap))
 
     host_s = {s: 0.0 for s in stages + ("finish",)}
+    # Three HIP streams: decode on the main stream; the NMS chain (short, latency-bound kernels that read the decoded
+    # tensor) on a second; assignment + loss forward/backward (bandwidth-bound, reads the raw maps and the logit plane
+    # the decode left behind) on a third.  Both wait for the step's decode; the next step's decode does not wait for them.
+    n_streams = 1 if use_graph else args.streams
+    overlap = n_streams > 1
+    torch.cuda.synchronize()
+    if overlap:      # keep the legacy null stream (which the runtime orders against every other stream) out of the loop
+        torch.cuda.set_stream(torch.cuda.Stream())
+    main_stream = torch.cuda.current_stream()
+    nms_stream = torch.cuda.Stream() if overlap else main_stream
+    loss_stream = torch.cuda.Stream() if n_streams == 3 else main_stream
+    set_stream = torch.cuda.set_stream
+    assign_early = overlap and os.environ.get("DH_BENCH_ASSIGN_EARLY", "0") == "1"
 
     def launch(record):
         """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation."""
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(len(stages) + 1)] if record else None
+        marks = mark_pool.pop() if record else None
         h0 = time.perf_counter()
+        assignment = None
+        if assign_early:      # target assignment needs only the targets: enqueue it beside the decode
+            set_stream(nms_stream)
+            assignment = crit.assign(level_shapes, targets)
+            assigned = torch.cuda.Event()
+            assigned.record()
+            set_stream(main_stream)
         if record: marks[0].record()
         z = g_decode.replay() if use_graph else f_decode()
         if record: marks[1].record()
         h1 = time.perf_counter()
-        loss, items, grads, stats = g_loss.replay() if use_graph else f_loss()
-        if record: marks[2].record()
-        h2 = time.perf_counter()
-        rows, meta, _ = g_nms.replay() if use_graph else nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
+        if overlap:
+            decoded = torch.cuda.Event()
+            decoded.record()
+            nms_stream.wait_event(decoded)
+            if n_streams == 3:
+                loss_stream.wait_event(decoded)
+            set_stream(nms_stream)
         if record: marks[3].record()
+        rows, meta, _ = g_nms.replay() if use_graph else nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
+        if record: marks[4].record()
+        host_meta, copied = nms_meta_to_host(meta)           # the step's only device-to-host copy (3*bs ints)
+        if record: marks[5].record()
+        h2 = time.perf_counter()
+        if overlap:
+            set_stream(loss_stream)
+            if assign_early:
+                loss_stream.wait_event(assigned)
+        if record: marks[6].record()
+        loss, items, grads, stats = g_loss.replay() if use_graph else f_loss(assignment)
         h3 = time.perf_counter()
         if world > 1:
             stats = stats.clone() if backend == "nccl" else stats.cpu()   # (host tensor only in the gloo rehearsal)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)          # [lbox, lobj, lcls, n_pos] over RCCL
-        host_meta, copied = nms_meta_to_host(meta)               # the step's only device-to-host copy (3*bs ints)
-        if record: marks[4].record()
+        if record: marks[2].record()
+        if overlap:
+            set_stream(main_stream)
         h4 = time.perf_counter()
         if record:
-            for s, d in zip(stages, (h1 - h0, h2 - h1, h3 - h2, h4 - h3)):
+            for s, d in zip(stages, (h1 - h0, h4 - h2, h2 - h1, 0.0)):
                 host_s[s] += d
-        return dict(marks=marks, rows=rows, host_meta=host_meta, copied=copied, loss=loss, grads=grads, stats=stats)
+        return dict(marks=marks, z=z, assignment=assignment, rows=rows, host_meta=host_meta, copied=copied, loss=loss, grads=grads, stats=stats)
 
     def finish(job):
         """Host half of a step: wait for that step's copy only, then build the per-image detection views."""
@@ -233,10 +274,14 @@ def main():
         host_s["finish"] += time.perf_counter() - h0
         return dets
 
+    step_wall = []
+
     def run(n, record):
         """n steps, software-pipelined: the host half of step i runs while the GPU works on step i+1."""
         all_marks, prev, dets = [], None, None
         for _ in range(n):
+            if record:
+                step_wall.append(time.perf_counter())
             job = launch(record)
             if prev is not None:
                 dets = finish(prev)      # prev's tensors are released here, so the allocator reuses its blocks
@@ -252,14 +297,24 @@ def main():
         torch.cuda.synchronize()
 
     run(args.warmup, False)
+    # timing events are created (and recorded once, which is what allocates them) outside the timed region
+    mark_pool = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
+    for marks in mark_pool:
+        for m in marks:
+            m.record()
+    import gc
+    gc.collect()
+    if not os.environ.get("DH_BENCH_KEEP_GC"):
+        gc.disable()      # a serving loop does not want a cyclic-GC pause in the middle of a step
     sync_all()
     t0 = time.perf_counter()
     all_marks, dets = run(args.steps, True)
     sync_all()
     elapsed = time.perf_counter() - t0
-    for marks in all_marks:
-        for i, s in enumerate(stages):
-            ev[s].append(marks[i].elapsed_time(marks[i + 1]))
+    gc.enable()
+    for marks in all_marks:     # decode and loss are bracketed on the main stream, nms and the copy on the stream they ran on
+        for s, (a, b) in zip(stages, ((0, 1), (6, 2), (3, 4), (4, 5))):
+            ev[s].append(marks[a].elapsed_time(marks[b]))
     if world > 1:
         tmax = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -291,7 +346,13 @@ def main():
                        "planted_positive_rows": n_planted, "detections_last_step": int(sum(d.shape[0] for d in dets))},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "host_enqueue_ms": {k: round(v / args.steps * 1e3, 4) for k, v in host_s.items()},
+            "host_step_interval_ms": {k: round(float(v) * 1e3, 4) for k, v in zip(
+                ("p10", "p50", "p90", "max", "argmax"), list(np.percentile(np.diff(step_wall), (10, 50, 90, 100))) +
+                [int(np.argmax(np.diff(step_wall))) * 1e-3])} if len(step_wall) > 2 else None,
             "launch_mode": "hip-graph per stage" if use_graph else "eager",
+            "loss_call": "crit(p,t) + torch.autograd.grad" if args.autograd else "crit.forward_backward(p,t)",
+            "streams": {1: "one stream", 2: "decode, assign+loss | nms chain on two streams (stage_ms overlap)",
+                        3: "decode | nms chain | assign+loss on three streams (stage_ms overlap)"}[n_streams],
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -64,9 +64,13 @@ int dh_centernet_box_loss_bwd(const float* pred_xy, int64_t pred_xy_bstride, con
  * arrays of nl entries; anchor_px is host (nl,na,2) = anchors[l]*stride[l] as _make_grid forms it;
  * level l input is (bs,na,ny,nx,no) contiguous on the device.  obj_plane (optional, may be NULL):
  * (bs, A) floats that receive a compact copy of the decoded objectness column out[:, :, 4], which
- * dh_nms_batched can read instead of the 340-byte-strided column. */
+ * dh_nms_batched can read instead of the 340-byte-strided column.  obj_logit_plane (optional, needs
+ * obj_plane): (bs, A) floats that receive the raw objectness logits (input channel 4, same row order),
+ * which dh_yolo_loss_fwd can read instead of the strided input column when the loss is evaluated on the
+ * same maps (as val.py does: object_detection/yolov5/val.py:194-198). */
 int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
-                   const float* anchor_px, const float* strides, float* out, float* obj_plane, void* stream);
+                   const float* anchor_px, const float* strides, float* out, float* obj_plane, float* obj_logit_plane,
+                   void* stream);
 
 /* Batched non_max_suppression (object_detection/yolov5/utils/general.py:647-738) over
  * pred (bs, A, 5+nc) = [x,y,w,h,obj,cls...].  Output rows are [x1,y1,x2,y2,conf,cls] in the
@@ -129,12 +133,15 @@ typedef struct dh_yolo_hyp {
  * ignored because their image/anchor index was outside the maps.  The forward leaves in `workspace` what the backward needs (per-row IoU and
  * the cell-owner map), so the same workspace must be passed to dh_yolo_loss_bwd unmodified.
  * The backward writes every element of every grad_p[l] (no pre-zeroing needed); grad_loss is the
- * upstream gradient of out[0] (1 float, device). */
+ * upstream gradient of out[0] (1 float, device).
+ * obj_logits: NULL, or the (bs, sum_l na*ny*nx) plane dh_yolo_decode wrote for exactly these maps
+ * (obj_logits[b][first_l + (a*ny+gj)*nx+gi] == p[l][b][a][gj][gi][4] bit for bit); the dense objectness
+ * pass then reads it instead of the strided column. */
 size_t dh_yolo_loss_workspace(const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t cap);
 int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                      const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
-                     int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace, size_t workspace_bytes,
-                     void* stream);
+                     int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
 int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                      const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
                      int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_p,

@@ -31,7 +31,7 @@ SIGNATURES = {
                                           c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                           c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
     "dh_yolo_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "dh_nms_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dh_nms_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p, c_int, c_int,
                                c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -45,7 +45,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_loss_workspace": (c_size_t, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64]),
     "dh_yolo_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                 c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_box_iou": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
@@ -82,8 +82,42 @@ def check(rc, name):
         raise RuntimeError(f"{name} failed: {ERRORS.get(rc, rc)}")
 
 
+_get_device = torch._C._cuda_getDevice
+_set_device = torch._C._cuda_setDevice
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
+def raw_stream():
+    """Handle (an integer) of torch's current HIP stream on the current device."""
+    return _raw_stream(_get_device())
+
+
 def stream():
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream on the current device, as the void* the C ABI takes."""
+    return c_void_p(_raw_stream(_get_device()))
+
+
+class device_guard:
+    """`with device_guard(t.device):` makes that device current for the launches inside; when it already is
+    (the usual case: one process per GPU) entering and leaving cost two integer compares."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index if device.index is not None else _get_device()
+        self.prev = -1
+
+    def __enter__(self):
+        prev = _get_device()
+        if prev != self.idx:
+            _set_device(self.idx)
+            self.prev = prev
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            _set_device(self.prev)
+            self.prev = -1
+        return False
 
 
 def ptr(t):
@@ -110,8 +144,18 @@ class YoloHyp(ctypes.Structure):
         ("balance", c_float * 5)]
 
 
+_ARRAYS = {}
+
+
 def int_array(values):
-    return (c_int * len(values))(*[int(v) for v in values])
+    """Read-only C int array of `values` (cached: the same few shapes recur every step)."""
+    key = ("i",) + tuple(int(v) for v in values)
+    hit = _ARRAYS.get(key)
+    if hit is None:
+        if len(_ARRAYS) > 256:
+            _ARRAYS.clear()
+        hit = _ARRAYS[key] = (c_int * (len(key) - 1))(*key[1:])
+    return hit
 
 
 def float_array(values):

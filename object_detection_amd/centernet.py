@@ -18,7 +18,7 @@ def pool_nms(heat, kernel=3):
     if h.dim() != 4:
         raise RuntimeError(f"pool_nms: expected (B,C,W,H), got {tuple(heat.shape)}")
     out = torch.empty_like(h)
-    with torch.cuda.device(h.device):
+    with L.device_guard(h.device):
         L.check(L.lib().dh_centernet_pool_nms(L.ptr(h), L.ptr(out), h.shape[0] * h.shape[1], h.shape[2], h.shape[3],
                                               int(kernel), L.stream()), "dh_centernet_pool_nms")
     return out
@@ -41,7 +41,7 @@ def decode_bbox(pred_cls, pred_size, pred_offset, confidence, device=None):
     ws = L.workspace(ws_bytes, heat.device)
     det = torch.empty((B, W * H, 6), dtype=torch.float32, device=heat.device)
     counts = torch.empty(B, dtype=torch.int32, device=heat.device)
-    with torch.cuda.device(heat.device):
+    with L.device_guard(heat.device):
         L.check(lib.dh_centernet_decode(L.ptr(heat), L.ptr(size), L.ptr(off), B, C, W, H, float(confidence), L.ptr(det),
                                         L.ptr(counts), L.ptr(ws), ws_bytes, L.stream()), "dh_centernet_decode")
     return [det[i, :k] if k else [] for i, k in enumerate(counts.tolist())]
@@ -115,7 +115,7 @@ def centernet_targets(labels, num_classes, input_shape, output_shape, device=Non
     t_off = torch.empty((B, 2, W, H), dtype=torch.float32, device=dev)
     t_mask = torch.empty((B, W, H), dtype=torch.float32, device=dev)
     owner = torch.empty((B, W, H), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         L.check(L.lib().dh_centernet_targets(L.ptr(packed), L.ptr(nl), B, lmax, float(input_shape[0]), float(input_shape[1]),
                                              int(num_classes), W, H, L.ptr(t_cls), L.ptr(t_size), L.ptr(t_off),
                                              L.ptr(t_mask), L.ptr(owner), L.stream()), "dh_centernet_targets")

@@ -32,6 +32,7 @@ struct decode_params {
     uint32_t per_image;   // elements of one image's output span = A*no
     uint32_t rows_per_image;
     float* obj_plane;     // optional (bs, A) copy of the objectness column, or nullptr
+    float* logit_plane;   // optional (bs, A) copy of the raw objectness logit (input channel 4), or nullptr
 };
 
 // box channels (c < 4) of row `row`: xy = (2s - 0.5 + grid) * stride, wh = (2s)^2 * anchor_px
@@ -101,7 +102,9 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
                 if (k4 < 0) { k4 += (int)no; r4 = row + 1; }
                 if (k4 < 4) {
                     const float ov = k4 == 0 ? y[0] : (k4 == 1 ? y[1] : (k4 == 2 ? y[2] : y[3]));
-                    P.obj_plane[(size_t)b * P.rows_per_image + L.row_first + r4] = ov;
+                    const size_t at = (size_t)b * P.rows_per_image + L.row_first + r4;
+                    P.obj_plane[at] = ov;
+                    if (P.logit_plane) P.logit_plane[at] = k4 == 0 ? x[u].x : (k4 == 1 ? x[u].y : (k4 == 2 ? x[u].z : x[u].w));
                 }
             }
             const dh_f4 o = {y[0], y[1], y[2], y[3]};
@@ -113,11 +116,15 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
             const uint32_t v = v0 + u * 256;
             if (v >= nvec) continue;
-            float y = dh_sigmoid(src[v]);
+            const float xv = src[v];
+            float y = dh_sigmoid(xv);
             const uint32_t row = dh_div(v, P.no);
             const uint32_t c = v - row * no;
             if (c < 4) y = decode_box(L, row, c, y);
-            if (c == 4 && P.obj_plane) P.obj_plane[(size_t)b * P.rows_per_image + L.row_first + row] = y;
+            if (c == 4 && P.obj_plane) {
+                P.obj_plane[(size_t)b * P.rows_per_image + L.row_first + row] = y;
+                if (P.logit_plane) P.logit_plane[(size_t)b * P.rows_per_image + L.row_first + row] = xv;
+            }
             dst[v] = y;
         }
     }
@@ -127,7 +134,7 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
 
 extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
                               int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
-                              void* stream)
+                              float* obj_logit_plane, void* stream)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 5 || bs < 0 || bs > 65535) return DH_ERR_ARG;
     if (!level_ptrs || !ny || !nx || !anchor_px || !strides || (bs > 0 && !out)) return DH_ERR_ARG;
@@ -157,7 +164,9 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
     }
     P.per_image = (uint32_t)first;
     P.rows_per_image = row_first;
+    if (obj_logit_plane && !obj_plane) return DH_ERR_ARG;   // the logit copy rides on the objectness-plane path
     P.obj_plane = obj_plane;
+    P.logit_plane = obj_logit_plane;
     const int vec = vec4 ? 4 : 1;
     static int unroll = 0, nt = 0;
     if (unroll == 0) {   // tuning knobs (defaults are the measured best)

@@ -24,6 +24,8 @@ struct yl_level {
     int ny, nx;
     long cells;          // bs*na*ny*nx
     long cell_first;     // offset of this level in the owner map
+    dh_fastdiv per_image;   // na*ny*nx
+    uint32_t row_first;  // first row of this level inside one image of the decoded (bs, A) planes
     unsigned blocks;     // dense-pass blocks of this level
     float balance;
 };
@@ -31,6 +33,7 @@ struct yl_level {
 struct yl_params {
     yl_level lvl[DH_MAX_LEVELS];
     int nl, bs, na, nc, no;
+    uint32_t rows_per_image;   // A = sum over levels of na*ny*nx
     long cap;
     float box, obj, cls, cls_pw, obj_pw, gamma, cp, cn, gr;
 };
@@ -149,7 +152,7 @@ __device__ __forceinline__ float tobj_of(const yl_params& P, int own, const floa
 
 __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int* __restrict__ owner,
                                                     const float* __restrict__ iou_ws, double* __restrict__ partial,
-                                                    float* __restrict__ dobj)
+                                                    float* __restrict__ dobj, const float* __restrict__ logits)
 {
     unsigned blk = blockIdx.x;
     const int l = level_of_block(P, blk);
@@ -161,7 +164,13 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
     for (int u = 0; u < OBJ_CELLS_PER_BLOCK / 256; ++u) {
         const long cell = (long)blk * OBJ_CELLS_PER_BLOCK + u * 256 + threadIdx.x;
         if (cell < L.cells) {
-            const float x = L.p[(size_t)cell * P.no + 4];
+            float x;
+            if (logits) {      // compact copy of the logits in decoded-row order: (bs, A)
+                const uint32_t b = dh_div((uint32_t)cell, L.per_image);
+                x = logits[(size_t)b * P.rows_per_image + L.row_first + ((uint32_t)cell - b * L.per_image.d)];
+            } else {
+                x = L.p[(size_t)cell * P.no + 4];
+            }
             const float t = tobj_of(P, own_l[cell], iou_l);
             acc += (double)bce_value(x, t, P.obj_pw, P.gamma);                                     // loss.py:155
             // the backward needs d BCE / d logit of every anchor: keep it compact (4 B per anchor) so that
@@ -260,8 +269,12 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const flo
 #pragma unroll
             for (int k = 0; k < VEC; ++k) if (k == k4) o[k] = g;
         }
-        if (VEC == 4) *reinterpret_cast<float4*>(L.g + e) = make_float4(o[0], o[1], o[2], o[3]);
-        else L.g[e] = o[0];
+        if (VEC == 4) {      // write-once stream: keep it out of the caches the next kernels want
+            const dh_f4 ov = {o[0], o[1], o[2], o[3]};
+            __builtin_nontemporal_store(ov, reinterpret_cast<dh_f4*>(L.g + e));
+        } else {
+            L.g[e] = o[0];
+        }
     }
 }
 
@@ -326,9 +339,13 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
     }
     long first = 0;
     unsigned blocks = 0;
+    uint32_t row_first = 0;
     for (int l = 0; l < nl; ++l) {
         if (ny[l] < 1 || nx[l] < 1) return false;
         yl_level& L = P.lvl[l];
+        L.per_image = dh_make_fastdiv((uint32_t)(na * ny[l] * nx[l]));
+        L.row_first = row_first;
+        row_first += (uint32_t)(na * ny[l] * nx[l]);
         L.p = p ? p[l] : nullptr;
         L.g = g ? g[l] : nullptr;
         L.ny = ny[l]; L.nx = nx[l];
@@ -346,6 +363,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
         blocks += L.blocks;
         L.balance = hyp ? hyp->balance[l] : 0.0f;
     }
+    P.rows_per_image = row_first;
     W.cells_total = first;
     // workspace layout is independent of grad_blocks: obj_blocks is always the forward count
     unsigned fwd_blocks = 0;
@@ -382,8 +400,8 @@ extern "C" size_t dh_yolo_loss_workspace(const int* ny, const int* nx, int nl, i
 
 extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                                 const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
-                                const int* counts, int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace,
-                                size_t workspace_bytes, void* stream)
+                                const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream)
 {
     yl_params P;
     yl_ws W;
@@ -406,7 +424,7 @@ extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int*
         hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
                            anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
     hipLaunchKernelGGL(k_yl_obj_fwd, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
-                       (float*)(ws + W.off_dobj));
+                       (float*)(ws + W.off_dobj), obj_logits);
     hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(FINAL_THREADS), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
     return dh_launch_status();
 }

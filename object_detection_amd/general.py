@@ -18,7 +18,7 @@ def _convert(x, mode):
         if src.stride(1) != 1:
             src = src.contiguous()
         y = src.clone(memory_format=torch.contiguous_format)
-        with torch.cuda.device(src.device):
+        with L.device_guard(src.device):
             L.check(L.lib().dh_box_convert(L.ptr(src), src.stride(0), L.ptr(y), y.stride(0), src.shape[0], mode,
                                            L.stream()), "dh_box_convert")
         return y if x.dtype == torch.float32 else y.to(x.dtype)
@@ -49,7 +49,7 @@ def _scale_clip(boxes, do_scale, pad, gain, shape):
                            f"{boxes.dtype} on {boxes.device}")
     if boxes.dim() != 2 or boxes.shape[1] < 4 or boxes.stride(1) != 1:
         raise RuntimeError(f"expected a row-major (n, >=4) view, got shape {tuple(boxes.shape)} stride {boxes.stride()}")
-    with torch.cuda.device(boxes.device):
+    with L.device_guard(boxes.device):
         L.check(L.lib().dh_scale_clip_coords(L.ptr(boxes), boxes.stride(0), boxes.shape[0], int(do_scale), float(pad[0]),
                                              float(pad[1]), float(gain), float(shape[1]), float(shape[0]), L.stream()),
                 "dh_scale_clip_coords")
@@ -134,7 +134,7 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     meta = torch.empty(3 * bs, dtype=torch.int32, device=dev)
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
                                    int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap,
                                    L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs), L.ptr(ws),

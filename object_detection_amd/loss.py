@@ -41,7 +41,7 @@ def _loss_forward(pxy, pwh, txy, twh, m, add_coords):
     ws_bytes = lib.dh_centernet_box_loss_workspace(B, W, H)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pxy.device)
     out2 = torch.empty(2, dtype=torch.float32, device=pxy.device)
-    with torch.cuda.device(pxy.device):
+    with L.device_guard(pxy.device):
         L.check(lib.dh_centernet_box_loss_fwd(L.ptr(pxy), pxy.stride(0), L.ptr(pwh), pwh.stride(0), L.ptr(txy),
                                               txy.stride(0), L.ptr(twh), twh.stride(0), L.ptr(m), B, W, H,
                                               int(add_coords), _EPS, L.ptr(out2), L.ptr(ws), ws_bytes, L.stream()),
@@ -52,7 +52,7 @@ def _loss_forward(pxy, pwh, txy, twh, m, add_coords):
 def _loss_backward(pxy, pwh, txy, twh, m, add_coords, out2, grad_out, gxy, gwh):
     B, _, W, H = pxy.shape
     g = grad_out.reshape(1).float().contiguous()
-    with torch.cuda.device(pxy.device):
+    with L.device_guard(pxy.device):
         L.check(L.lib().dh_centernet_box_loss_bwd(L.ptr(pxy), pxy.stride(0), L.ptr(pwh), pwh.stride(0), L.ptr(txy),
                                                   txy.stride(0), L.ptr(twh), twh.stride(0), L.ptr(m), B, W, H,
                                                   int(add_coords), _EPS, L.ptr(out2), L.ptr(g), L.ptr(gxy),

@@ -30,7 +30,7 @@ class _PairIoU(torch.autograd.Function):
         out = torch.empty(n, dtype=torch.float32, device=b1.device)
         s1c, s1e = _layout(b1, comp1, 1 - comp1)
         s2c, s2e = _layout(b2, comp2, 1 - comp2)
-        with torch.cuda.device(b1.device):
+        with L.device_guard(b1.device):
             L.check(L.lib().dh_bbox_iou_fwd(L.ptr(b1), s1c, s1e, L.ptr(b2), s2c, s2e, L.ptr(out), n, int(xyxy), mode,
                                             float(eps), L.stream()), "dh_bbox_iou_fwd")
         ctx.save_for_backward(b1, b2)
@@ -49,7 +49,7 @@ class _PairIoU(torch.autograd.Function):
         s1c, s1e = _layout(b1, comp1, 1 - comp1)
         s2c, s2e = _layout(b2, comp2, 1 - comp2)
         sgc, sge = _layout(grad1, comp1, 1 - comp1)
-        with torch.cuda.device(b1.device):
+        with L.device_guard(b1.device):
             L.check(L.lib().dh_bbox_iou_bwd(L.ptr(b1), s1c, s1e, L.ptr(b2), s2c, s2e, L.ptr(g), L.ptr(grad1), sgc, sge,
                                             n, xyxy, mode, eps, L.stream()), "dh_bbox_iou_bwd")
         return grad1.to(dtype), None, None, None, None, None, None
@@ -68,7 +68,7 @@ def _pairwise(name, a, b, width):
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != width or b.shape[1] != width:
         raise RuntimeError(f"{name}: expected (N,{width}) and (M,{width}), got {tuple(a.shape)} and {tuple(b.shape)}")
     out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with L.device_guard(a.device):
         L.check(getattr(L.lib(), "dh_" + name)(L.ptr(a), L.ptr(b), L.ptr(out), a.shape[0], b.shape[0], L.stream()),
                 "dh_" + name)
     return out

@@ -24,7 +24,7 @@ def nms(boxes, scores, iou_threshold):
     ws = L.workspace(ws_bytes, b.device)
     keep = torch.empty(n, dtype=torch.int64, device=b.device)
     count = torch.empty(1, dtype=torch.int32, device=b.device)
-    with torch.cuda.device(b.device):
+    with L.device_guard(b.device):
         L.check(lib.dh_nms_plain(L.ptr(b), L.ptr(s), n, float(iou_threshold), L.ptr(keep), L.ptr(count), L.ptr(ws),
                                  ws_bytes, L.stream()), "dh_nms_plain")
     return keep[:int(count.item())]

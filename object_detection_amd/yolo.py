@@ -9,6 +9,7 @@ from . import _lib as L
 
 _ANCHOR_CACHE = {}
 _OBJ_PLANES = {}    # data_ptr of a decoded tensor -> (weakref to it, its version counter, compact objectness (bs, A))
+_LOGIT_PLANES = {}  # data_ptr of the first raw map -> ([(weakref, version, shape) per map], raw objectness logits (bs, A))
 
 
 def objectness_plane(pred):
@@ -20,10 +21,38 @@ def objectness_plane(pred):
     hit = _OBJ_PLANES.get(pred.data_ptr())
     if hit is None:
         return None
-    ref, version, plane = hit
+    ref, version, plane, made_on = hit
     if ref() is pred and pred._version == version and plane.shape == pred.shape[:2]:
-        return plane
+        return _borrow(plane, made_on)
     return None
+
+
+def _borrow(plane, made_on):
+    """A plane is written on the stream detect_decode ran on; a reader on another stream has to tell the
+    caching allocator, or the block could be handed out again while that stream still reads it."""
+    if L._raw_stream(plane.device.index) != made_on:
+        plane.record_stream(torch.cuda.current_stream(plane.device))
+    return plane
+
+
+def objectness_logits(maps):
+    """The compact copy of the objectness logits (channel 4 of every map, decoded row order, (bs, A)) that
+    detect_decode wrote when it last read exactly these maps, or None.
+
+    Valid only while every map still is the storage detect_decode read (the tensor it saw is alive, same
+    address, shape and version counter, i.e. no in-place write since), so reading it is reading the maps.
+    """
+    if not maps:
+        return None
+    hit = _LOGIT_PLANES.get(maps[0].data_ptr())
+    if hit is None or len(hit[0]) != len(maps):
+        return None
+    for x, (ref, version, shape) in zip(maps, hit[0]):
+        seen = ref()
+        if (seen is None or seen.data_ptr() != x.data_ptr() or x._version != version or seen._version != version
+                or tuple(x.shape) != shape or x.dtype != torch.float32 or not x.is_contiguous()):
+            return None
+    return _borrow(hit[1], hit[2])
 
 
 def _anchor_pixels(anchors, stride):
@@ -58,17 +87,25 @@ def detect_decode(levels, anchors, stride):
     total = sum(na * a * b for a, b in zip(ny, nx))
     anchor_px, strides = _anchor_pixels(anchors, stride)
     out = torch.empty((bs, total, no), dtype=torch.float32, device=xs[0].device)
-    plane = torch.empty((bs, total), dtype=torch.float32, device=xs[0].device)
+    planes = torch.empty((2, bs, total), dtype=torch.float32, device=xs[0].device)
+    plane, logits = planes[0], planes[1]
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
-    with torch.cuda.device(out.device):
+    with L.device_guard(out.device):
+        made_on = L.raw_stream()
         L.check(L.lib().dh_yolo_decode(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
-                                       L.ptr(out), L.ptr(plane), L.stream()), "dh_yolo_decode")
+                                       L.ptr(out), L.ptr(plane), L.ptr(logits), L.c_void_p(made_on)), "dh_yolo_decode")
     if len(_OBJ_PLANES) > 8:
         for k in [k for k, v in _OBJ_PLANES.items() if v[0]() is None]:
             del _OBJ_PLANES[k]
         if len(_OBJ_PLANES) > 8:
             _OBJ_PLANES.clear()
-    _OBJ_PLANES[out.data_ptr()] = (weakref.ref(out), out._version, plane)
+    _OBJ_PLANES[out.data_ptr()] = (weakref.ref(out), out._version, plane, made_on)
+    if len(_LOGIT_PLANES) > 8:
+        for k in [k for k, v in _LOGIT_PLANES.items() if any(r() is None for r, _, _ in v[0])]:
+            del _LOGIT_PLANES[k]
+        if len(_LOGIT_PLANES) > 8:
+            _LOGIT_PLANES.clear()
+    _LOGIT_PLANES[xs[0].data_ptr()] = ([(weakref.ref(x), x._version, tuple(x.shape)) for x in xs], logits, made_on)
     return out
 
 

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from .yolo import objectness_logits
 
 
 def smooth_BCE(eps=0.1):
@@ -31,6 +32,15 @@ class _Assignment:
         self.anch = torch.empty((nl, rows, 2), dtype=torch.float32, device=device)
         self.tcls = torch.empty((nl, rows), dtype=torch.int64, device=device)
         self.counts = torch.empty(nl, dtype=torch.int32, device=device)
+        self.made_on = L._raw_stream(device.index)      # the stream the assignment kernel is enqueued on
+
+    def borrow(self):
+        """Called by a consumer: when it runs on another stream than the producer, the caching allocator has to know."""
+        dev = self.counts.device
+        if L._raw_stream(dev.index) != self.made_on:
+            cur = torch.cuda.current_stream(dev)
+            for t in (self.idx, self.tbox, self.anch, self.tcls, self.counts):
+                t.record_stream(cur)
 
 
 def _assign(level_shapes, targets, anchors, anchor_t):
@@ -44,7 +54,7 @@ def _assign(level_shapes, targets, anchors, anchor_t):
     lib = L.lib()
     ws_bytes = lib.dh_build_targets_workspace(nl, na, A.nt)
     ws = L.workspace(ws_bytes, tg.device)
-    with torch.cuda.device(tg.device):
+    with L.device_guard(tg.device):
         L.check(lib.dh_build_targets(L.ptr(tg), A.nt, L.ptr(anc), nl, na, L.int_array(A.ny), L.int_array(A.nx),
                                      float(anchor_t), A.cap, L.ptr(A.idx), L.ptr(A.tbox), L.ptr(A.anch), L.ptr(A.tcls),
                                      L.ptr(A.counts), L.ptr(ws), ws_bytes, L.stream()), "dh_build_targets")
@@ -67,10 +77,13 @@ def _loss_fwd(assign, hyp, nc, maps):
     ws = L.workspace(ws_bytes, dev)
     out = torch.empty(6 + nl, dtype=torch.float32, device=dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
-    with torch.cuda.device(dev):
+    # when the inference decode has just read these very maps (validation: val.py:194-198 evaluates the loss on the
+    # maps it decoded), it left a compact copy of their objectness logits; read that instead of the strided column
+    logits = objectness_logits(maps)
+    with L.device_guard(dev):
         L.check(lib.dh_yolo_loss_fwd(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
                                      L.ptr(assign.anch), L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap,
-                                     ctypes.byref(hyp), L.ptr(out), L.ptr(ws), ws_bytes, L.stream()),
+                                     ctypes.byref(hyp), L.ptr(logits), L.ptr(out), L.ptr(ws), ws_bytes, L.stream()),
                 "dh_yolo_loss_fwd")
     return out, ws
 
@@ -82,12 +95,23 @@ def _loss_bwd(assign, hyp, nc, maps, ws, g_loss):
     grads = [torch.empty_like(x) for x in maps]
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
-    with torch.cuda.device(maps[0].device):
+    with L.device_guard(maps[0].device):
         L.check(L.lib().dh_yolo_loss_bwd(ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc,
                                          L.ptr(assign.idx), L.ptr(assign.tbox), L.ptr(assign.anch),
                                          L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap, ctypes.byref(hyp),
                                          L.ptr(g_loss), gptrs, L.ptr(ws), ws.numel(), L.stream()), "dh_yolo_loss_bwd")
     return grads
+
+
+_ONES = {}
+
+
+def _one(device):
+    """A resident 1.0 per device: the default upstream gradient."""
+    hit = _ONES.get(device)
+    if hit is None:
+        hit = _ONES[device] = torch.ones(1, dtype=torch.float32, device=device)
+    return hit
 
 
 class _YoloLoss(torch.autograd.Function):
@@ -141,11 +165,28 @@ class ComputeLoss:
             s.balance[i] = float(b)
         return s
 
-    def __call__(self, p, targets):
+    def assign(self, p, targets):
+        """Target assignment only (loss.py:169-222), kept on the device: the opaque result can be handed to
+        __call__ / forward_backward as `assignment=` so that this short, latency-bound kernel can be enqueued early
+        (e.g. on another stream, beside the kernels that produce or decode `p`).  p may be the maps or their
+        (ny, nx) shapes."""
+        shapes = [(x.shape[2], x.shape[3]) if isinstance(x, torch.Tensor) else (int(x[0]), int(x[1])) for x in p]
+        return _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+
+    def _assignment_for(self, shapes, targets, assignment):
+        if assignment is None:
+            return _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+        if not isinstance(assignment, _Assignment) or list(zip(assignment.ny, assignment.nx)) != [tuple(s) for s in shapes] \
+                or assignment.nt != int(targets.shape[0]):
+            raise RuntimeError("assignment= was not produced by ComputeLoss.assign for these maps and targets")
+        assignment.borrow()
+        return assignment
+
+    def __call__(self, p, targets, assignment=None):
         if self.sort_obj_iou:
             raise NotImplementedError("sort_obj_iou=True is not supported (the reference never enables it, loss.py:94)")
-        shapes = [(x.shape[2], x.shape[3]) for x in p]
-        assign = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in p]
+        assign = self._assignment_for(shapes, targets, assignment)
         self.last_positive_counts = assign.counts            # (nl,) int32 on the device: rows assigned per level
         loss, rest = _YoloLoss.apply(assign, self._hyp_struct(), int(self.nc), *p)
         self.last_stats = rest[0:4]                                             # [lbox, lobj, lcls, n_pos] on the device
@@ -155,7 +196,7 @@ class ComputeLoss:
             self.balance = [x / self.balance[self.ssi] for x in self.balance]
         return loss, rest[0:3]
 
-    def forward_backward(self, p, targets, grad_loss=None):
+    def forward_backward(self, p, targets, grad_loss=None, assignment=None):
         """Loss and its gradients in one call, without the autograd engine: (loss[1], loss_items[3], [dL/dp_i]).
 
         Same kernels as __call__ followed by backward(); grad_loss (1 float on the device, default 1) is the
@@ -165,13 +206,13 @@ class ComputeLoss:
         if self.sort_obj_iou or self.autobalance:
             raise NotImplementedError("forward_backward supports neither sort_obj_iou nor autobalance")
         maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
-        shapes = [(x.shape[2], x.shape[3]) for x in maps]
-        assign = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in maps]
+        assign = self._assignment_for(shapes, targets, assignment)
         self.last_positive_counts = assign.counts
         hyp = self._hyp_struct()
         out, ws = _loss_fwd(assign, hyp, int(self.nc), maps)
         if grad_loss is None:
-            grad_loss = torch.ones(1, dtype=torch.float32, device=maps[0].device)
+            grad_loss = _one(maps[0].device)
         grads = _loss_bwd(assign, hyp, int(self.nc), maps, ws, grad_loss.reshape(1).float().contiguous())
         self.last_stats = out[1:5]
         return out[0:1], out[1:4], grads

@@ -164,3 +164,38 @@ def test_full_size_bs64_640_pipeline_vs_oracle():
         for g, w in zip(got, want):
             assert torch.equal(g.cpu(), w)
         assert sum(w.shape[0] for w in want) > 1000
+
+
+def test_loss_after_decode_reads_compact_logits_bit_exact():
+    """Validation evaluates the loss on the maps the decode has just read; the decode leaves a compact copy of the
+    objectness logits which the loss may read instead of the strided column.  Same values, so same bits."""
+    from object_detection_amd.yolo import detect_decode, objectness_logits
+    rs = np.random.RandomState(77)
+    anchors = oy.grid_anchors()
+    levels = [T(x).cuda() for x in synth_head(rs, 4, 320, 80)]
+    targets = T(synth_targets(rs, 40, 4)).cuda()
+    crit = make_loss(anchors, 80, dict(oy.HYP_SCRATCH))
+    p = [x.clone().requires_grad_(True) for x in levels]
+    assert objectness_logits(p) is None
+    l0, i0 = crit(p, targets)
+    g0 = torch.autograd.grad(l0, p)
+    detect_decode(p, anchors.cuda(), torch.tensor(oy.YOLOV5S_STRIDES))
+    plane = objectness_logits(p)
+    assert plane is not None and plane.shape == (4, 3 * (40 * 40 + 20 * 20 + 10 * 10))
+    want = torch.cat([x.detach()[..., 4].reshape(4, -1) for x in p], 1)
+    assert torch.equal(plane, want)
+    assert objectness_logits([x.detach() for x in p]) is plane      # another view of the same, unmodified storage
+    l1, i1 = crit(p, targets)
+    g1 = torch.autograd.grad(l1, p)
+    assert torch.equal(l0, l1) and torch.equal(i0, i1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # any in-place write to a map invalidates the copy, and the loss goes back to the strided column
+    with torch.no_grad():
+        p[1][0, 0, 0, 0, 4] += 3.0
+    assert objectness_logits(p) is None
+    l2, _ = crit(p, targets)
+    assert not torch.equal(l2, l1)
+    q = [x.detach().clone().requires_grad_(True) for x in p]
+    l3, _ = crit(q, targets)
+    assert torch.equal(l2, l3)

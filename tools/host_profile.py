@@ -46,4 +46,5 @@ for _ in range(100):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats("tottime").print_stats(45)
+st.sort_stats("cumulative").print_stats("object_detection_amd|bench|host_profile")
