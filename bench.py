@@ -181,7 +181,7 @@ def main():
     from object_detection_amd.graphs import GraphedStage
 
     use_graph = args.graph
-    stages = ("decode", "assign+loss_fwd+bwd+allreduce", "nms", "d2h")
+    stages = ("decode", "assign+loss_fwd+bwd", "nms", "d2h")
     ev = {s: [] for s in stages}
     cap = A
 
@@ -254,10 +254,15 @@ def main():
         if record: marks[6].record()
         loss, items, grads, stats = g_loss.replay() if use_graph else f_loss(assignment)
         h3 = time.perf_counter()
+        if record: marks[2].record()
         if world > 1:
             stats = stats.clone() if backend == "nccl" else stats.cpu()   # (host tensor only in the gloo rehearsal)
+            if overlap:      # the collective waits for the loss on the side stream: the next decode does not wait for the other ranks
+                reduced_after = torch.cuda.Event()
+                reduced_after.record()
+                set_stream(nms_stream)
+                nms_stream.wait_event(reduced_after)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)          # [lbox, lobj, lcls, n_pos] over RCCL
-        if record: marks[2].record()
         if overlap:
             set_stream(main_stream)
         h4 = time.perf_counter()
@@ -349,6 +354,7 @@ def main():
             "host_step_interval_ms": {k: round(float(v) * 1e3, 4) for k, v in zip(
                 ("p10", "p50", "p90", "max", "argmax"), list(np.percentile(np.diff(step_wall), (10, 50, 90, 100))) +
                 [int(np.argmax(np.diff(step_wall))) * 1e-3])} if len(step_wall) > 2 else None,
+            "collective": "one all_reduce(SUM) of [lbox, lobj, lcls, n_pos] per step over RCCL, on the side stream" if world > 1 else None,
             "launch_mode": "hip-graph per stage" if use_graph else "eager",
             "loss_call": "crit(p,t) + torch.autograd.grad" if args.autograd else "crit.forward_backward(p,t)",
             "streams": {1: "one stream", 2: "decode, assign+loss | nms chain on two streams (stage_ms overlap)",

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Wall-clock timings (device-synchronised) of the non-headline configurations:
+
+  val     bs 64 @640, NMS(conf 0.001, iou 0.6, multi_label)        -- validation-mode NMS of configuration 2
+  dense   bs 32 x 100000 boxes x 80 classes, NMS(0.25, 0.45)       -- dense pre-NMS stress (top-30000 cut)
+  sweep   16 images @1280 (100800 anchors), decode + NMS(0.001, 0.6, multi_label)  -- one GPU's share of the 1280 px sweep
+
+  python tools/time_configs.py [val,dense,sweep] [--iters 5]
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def wall(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3, out
+
+
+def dense_pred(bs, A, nc, dev, seed=3):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    pred = torch.empty((bs, A, 5 + nc), device=dev)
+    pred[..., 0:2] = torch.rand((bs, A, 2), generator=g, device=dev) * 640
+    pred[..., 2:4] = torch.exp(torch.rand((bs, A, 2), generator=g, device=dev) * (math.log(256) - math.log(4)) + math.log(4))
+    pred[..., 4] = torch.rand((bs, A), generator=g, device=dev) * 0.7 + 0.3
+    for b in range(bs):      # image by image: the softmax temporary of the whole batch would be another GB
+        pred[b, :, 5:] = torch.softmax(torch.randn((A, nc), generator=g, device=dev) * 3, -1)
+    return pred
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="?", default="val,dense,sweep")
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    which = set(args.which.split(","))
+    dev = torch.device("cuda", 0)
+    from object_detection_amd.general import non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    from object_detection_amd.yolo_loss import ComputeLoss
+    anchors = bench.grid_anchors(dev)
+    strides = torch.tensor([8., 16., 32.])
+
+    if "val" in which:
+        crit = ComputeLoss(bench._Model(anchors, 80))
+        levels, targets = bench.synth_batch(64, 640, 80, 640, 1000, dev)
+        bench.plant_objects(levels, targets, crit)
+        z = detect_decode(levels, anchors, strides)
+        ms, out = wall(lambda: non_max_suppression(z, 0.001, 0.6, multi_label=True), args.iters)
+        print(f"val   bs64@640 NMS(0.001,0.6,multi_label): {ms:8.3f} ms  ({64 / ms * 1e3:9.0f} img/s)  dets {sum(o.shape[0] for o in out)}", flush=True)
+        del levels, z
+    if "dense" in which:
+        pred = dense_pred(32, 100000, 80, dev)
+        ms, out = wall(lambda: non_max_suppression(pred, 0.25, 0.45, max_det=300), args.iters)
+        print(f"dense bs32x100k NMS(0.25,0.45): {ms:8.3f} ms  ({32 / ms * 1e3:9.0f} img/s)  dets {sum(o.shape[0] for o in out)}", flush=True)
+        del pred
+    if "sweep" in which:
+        gen = torch.Generator(device=dev).manual_seed(5)
+        levels = []
+        for s in bench.STRIDES:
+            n = 1280 // s
+            x = torch.randn((16, 3, n, n, 85), generator=gen, device=dev)
+            x[..., 4] += math.log(8 / (1280 / s) ** 2)
+            x[..., 5:] += math.log(0.6 / (80 - 0.999999))
+            levels.append(x)
+        ms_d, z = wall(lambda: detect_decode(levels, anchors, strides), args.iters)
+        ms_n, out = wall(lambda: non_max_suppression(z, 0.001, 0.6, multi_label=True), args.iters)
+        print(f"sweep 16img@1280 decode {ms_d:8.3f} ms ({680.0 * 100800 * 16 / ms_d / 1e6:7.1f} GB/s)  NMS(0.001,0.6,ml) {ms_n:8.3f} ms  "
+              f"({16 / (ms_d + ms_n) * 1e3:9.0f} img/s)  dets {sum(o.shape[0] for o in out)}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
