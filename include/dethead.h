@@ -170,6 +170,24 @@ int dh_centernet_targets(const float* labels, const int* nlabels, int B, int Lma
                          int W, int H, float* t_cls, float* t_size, float* t_offset, float* t_mask, int* owner_ws,
                          void* stream);
 
+/* Evaluation-time matching of detections to labels for a batch of images in one launch
+ * (object_detection/yolov5/val.py:71-92 process_batch; object_detection/yolov5/utils/metrics.py:125-163
+ * ConfusionMatrix.process_batch; both on the IoU of metrics.py:242-264).
+ * det (n_det, 6) rows [x1,y1,x2,y2,conf,cls] and labels (n_labels, 5) rows [cls,x1,y1,x2,y2] hold the images back to
+ * back; det_first / label_first (device, n_img+1 ints) give each image's row range, or NULL when n_img == 1.
+ * dh_eval_match: iouv (device, n_iou floats, ascending; iouv[0] is the pairing threshold) -> correct (n_det, n_iou)
+ * bytes 0/1.  dh_confusion_update: adds this batch's counts to matrix ((nc+1) x (nc+1) uint64 on the device,
+ * row = predicted class, column = true class, index nc = background), thresholds compared in fp32 as torch does.
+ * Equal IoUs are resolved as a stable argsort followed by [::-1] would (the reference's argsort is unstable).
+ * workspace: device, 256-byte aligned, dh_eval_match_workspace(n_det, n_labels) bytes. */
+size_t dh_eval_match_workspace(int64_t n_det, int64_t n_labels);
+int dh_eval_match(const float* det, const float* labels, const int* det_first, const int* label_first, int n_img,
+                  int64_t n_det, int64_t n_labels, const float* iouv, int n_iou, unsigned char* correct, void* workspace,
+                  size_t workspace_bytes, void* stream);
+int dh_confusion_update(const float* det, const float* labels, const int* det_first, const int* label_first, int n_img,
+                        int64_t n_det, int64_t n_labels, int nc, double conf, double iou_thres, unsigned long long* matrix,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

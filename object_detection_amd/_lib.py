@@ -54,6 +54,11 @@ SIGNATURES = {
     "dh_centernet_decode_workspace": (c_size_t, [c_int, c_int, c_int]),
     "dh_centernet_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_eval_match_workspace": (c_size_t, [c_i64, c_i64]),
+    "dh_eval_match": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_void_p, c_int, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    "dh_confusion_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_i64, c_i64, c_int, c_double, c_double,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_centernet_targets": (c_int, [c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

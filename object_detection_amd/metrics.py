@@ -93,3 +93,61 @@ def bbox_ioa(box1, box2, eps=1E-7):
     iw = (np.minimum(box1[2], box2[2]) - np.maximum(box1[0], box2[0])).clip(0)
     ih = (np.minimum(box1[3], box2[3]) - np.maximum(box1[1], box2[1])).clip(0)
     return iw * ih / ((box2[2] - box2[0]) * (box2[3] - box2[1]) + eps)
+
+
+class ConfusionMatrix:
+    """Drop-in for metrics.py:116-171 (matching + counting; plotting is not part of this package).
+
+    The counts live on the device as uint64 and are updated by one kernel launch per call with no device-to-host
+    copy; `.matrix` is the reference's float64 (nc+1, nc+1) numpy array, materialised when read.
+    """
+
+    def __init__(self, nc, conf=0.25, iou_thres=0.45):
+        self.nc = nc
+        self.conf = conf
+        self.iou_thres = iou_thres
+        self._counts = None
+
+    def _update(self, det, lab, det_first, label_first, n_img):
+        if self._counts is None:
+            self._counts = torch.zeros((self.nc + 1, self.nc + 1), dtype=torch.int64, device=det.device)
+        n_det, n_lab = int(det.shape[0]), int(lab.shape[0])
+        if n_det == 0 and n_lab == 0:
+            return
+        lib = L.lib()
+        ws_bytes = lib.dh_eval_match_workspace(n_det, n_lab)
+        ws = L.workspace(ws_bytes, det.device)
+        with L.device_guard(det.device):
+            L.check(lib.dh_confusion_update(L.ptr(det), L.ptr(lab), L.ptr(det_first), L.ptr(label_first), n_img, n_det, n_lab,
+                                            int(self.nc), float(self.conf), float(self.iou_thres), L.ptr(self._counts),
+                                            L.ptr(ws), ws_bytes, L.stream()), "dh_confusion_update")
+
+    def process_batch(self, detections, labels):
+        """One image: detections (N,6) [x1,y1,x2,y2,conf,cls], labels (M,5) [cls,x1,y1,x2,y2] (metrics.py:125-163)."""
+        from .val import _rows
+        self._update(_rows(detections, 6, "detections"), _rows(labels, 5, "labels"), None, None, 1)
+
+    def process_batches(self, detections, labels):
+        """All images of a batch in one launch (lists of per-image tensors)."""
+        from .val import _offsets, _rows
+        if len(detections) != len(labels):
+            raise RuntimeError("process_batches needs one label tensor per detection tensor")
+        if not detections:
+            return
+        dets = [_rows(d, 6, f"detections[{i}]") for i, d in enumerate(detections)]
+        labs = [_rows(t, 5, f"labels[{i}]") for i, t in enumerate(labels)]
+        det_first, _ = _offsets([d.shape[0] for d in dets], dets[0].device)
+        label_first, _ = _offsets([t.shape[0] for t in labs], dets[0].device)
+        self._update(torch.cat(dets), torch.cat(labs), det_first, label_first, len(dets))
+
+    @property
+    def matrix(self):
+        if self._counts is None:
+            return np.zeros((self.nc + 1, self.nc + 1))
+        return self._counts.cpu().numpy().astype(np.float64)
+
+    def tp_fp(self):
+        m = self.matrix
+        tp = m.diagonal()
+        fp = m.sum(1) - tp
+        return tp[:-1], fp[:-1]

@@ -278,3 +278,21 @@ def test_centernet_decode_and_postprocess(golden):
         assert (d is None) == (want.shape[0] == 0)
         if d is not None:
             close(d, want)
+
+
+EVAL_CASES = ["empty_det", "empty_lab", "one", "small", "crowd", "many", "loose", "ties"]
+
+
+@pytest.mark.parametrize("tag", EVAL_CASES)
+def test_evalmatch_oracle_vs_reference(golden, tag):
+    """val.py:71-92 and metrics.py:116-171: the fixture holds the reference's own outputs (the `ties` case, which has
+    equal IoUs, holds the stable refinement of its unstable sorts)."""
+    from oracle import evalmatch as oe
+    g = golden("evalmatch")
+    det, lab = torch.from_numpy(g[f"{tag}_det"]), torch.from_numpy(g[f"{tag}_labels"])
+    correct = oe.process_batch(det, lab, torch.from_numpy(g["iouv"]))
+    np.testing.assert_array_equal(correct.numpy(), g[f"{tag}_correct"])
+    cm = oe.ConfusionMatrix(nc=int(g[f"{tag}_meta"][0]))
+    cm.process_batch(det, lab)
+    cm.process_batch(det[::2], lab)
+    np.testing.assert_array_equal(cm.matrix, g[f"{tag}_matrix"])

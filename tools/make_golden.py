@@ -467,6 +467,79 @@ def gen_box_utils(y_general):
     save("box_utils", **out)
 
 
+def reference_process_batch(y_metrics):
+    """val.py cannot be imported (it pulls in the model zoo); its process_batch is a self-contained function, so the
+    function definition alone is compiled from the reference's file, at run time, with the names it uses bound to
+    the reference's own box_iou."""
+    import ast
+    path = os.path.join(REF, "yolov5", "val.py")
+    tree = ast.parse(open(path).read(), path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "process_batch"]
+    ns = {"torch": torch, "np": np, "box_iou": y_metrics.box_iou}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    return ns["process_batch"]
+
+
+def eval_case(rs, n_lab, n_det, nc, jitter, dup=False):
+    """labels (M,5) [cls, xyxy] and detections (N,6) [xyxy, conf, cls] around them, detections sorted by confidence."""
+    c = rs.uniform(40, 600, (n_lab, 2))
+    wh = np.exp(rs.uniform(np.log(12), np.log(200), (n_lab, 2)))
+    lab = np.concatenate((rs.randint(0, nc, (n_lab, 1)).astype(np.float64), c - wh / 2, c + wh / 2), 1)
+    src = rs.randint(0, max(n_lab, 1), n_det)
+    det = np.zeros((n_det, 6))
+    if n_lab:
+        det[:, :4] = lab[src, 1:] + rs.normal(0, jitter, (n_det, 4)) * np.tile(wh[src], 2)
+        det[:, 5] = np.where(rs.rand(n_det) < 0.8, lab[src, 0], rs.randint(0, nc, n_det))
+    else:
+        det[:, :4] = np.concatenate((rs.uniform(0, 300, (n_det, 2)), rs.uniform(300, 600, (n_det, 2))), 1)
+        det[:, 5] = rs.randint(0, nc, n_det)
+    det[:, 4] = np.sort(rs.uniform(0.001, 1, n_det))[::-1]
+    if dup and n_det > 4 and n_lab > 1:      # exact duplicates: equal IoUs (the stable refinement decides)
+        det[1, :4] = det[0, :4]
+        det[3, :4] = det[2, :4]
+        det[3, 5] = det[2, 5]
+        lab[1, 1:] = lab[0, 1:]
+    return f32(lab), f32(det)
+
+
+def gen_evalmatch(y_metrics):
+    """val.py:71-92 and metrics.py:116-171 on tie-free cases from the untouched reference, and on cases with equal IoUs
+    from the reference with its two argsorts made stable (the only change: numpy's argsort kind)."""
+    from oracle import evalmatch as oe
+    ref_pb = reference_process_batch(y_metrics)
+    iouv = torch.linspace(0.5, 0.95, 10)
+    rs = np.random.RandomState(4242)
+    out = {"iouv": iouv.numpy()}
+    cases = [("empty_det", 5, 0, 3, .05, False), ("empty_lab", 0, 7, 3, .05, False), ("one", 1, 1, 1, .02, False),
+             ("small", 6, 20, 3, .06, False), ("crowd", 40, 300, 5, .08, False), ("many", 120, 300, 80, .05, False),
+             ("loose", 25, 200, 2, .2, False), ("ties", 12, 60, 2, .05, True)]
+    for tag, n_lab, n_det, nc, jit, dup in cases:
+        lab, det = eval_case(rs, n_lab, n_det, nc, jit, dup)
+        tl, td = torch.from_numpy(lab), torch.from_numpy(det)
+        # The case with equal IoUs cannot be pinned by the untouched reference (ndarray.argsort's default kind is
+        # unstable and cannot be rebound): its expected values are the oracle's stable refinement, and whether the
+        # reference happens to agree on this numpy build is only printed.
+        if dup:
+            same = torch.equal(ref_pb(td, tl, iouv), oe.process_batch(td, tl, iouv))
+            print(f"  evalmatch {tag}: untouched reference {'agrees with' if same else 'differs from'} the stable refinement")
+        correct = ref_pb(td, tl, iouv) if not dup else oe.process_batch(td, tl, iouv)
+        mine = oe.process_batch(td, tl, iouv)
+        assert torch.equal(correct, mine), tag
+        cm = y_metrics.ConfusionMatrix(nc=nc) if not dup else oe.ConfusionMatrix(nc=nc)
+        cm.process_batch(td, tl)
+        cm.process_batch(td[::2], tl)            # a second image accumulates into the same matrix
+        mine_cm = oe.ConfusionMatrix(nc=nc)
+        mine_cm.process_batch(td, tl)
+        mine_cm.process_batch(td[::2], tl)
+        assert np.array_equal(cm.matrix, mine_cm.matrix), tag
+        out[f"{tag}_labels"], out[f"{tag}_det"] = lab, det
+        out[f"{tag}_correct"] = correct.numpy()
+        out[f"{tag}_matrix"] = cm.matrix
+        out[f"{tag}_meta"] = np.array([nc, int(dup)])
+        print(f"  evalmatch {tag}: {int(correct[:, 0].sum())} of {n_det} detections correct @0.5, matrix sum {cm.matrix.sum():.0f}")
+    save("evalmatch", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -479,6 +552,7 @@ def main():
     gen_compute_loss(y_loss)
     gen_nms(y_general)
     gen_centernet(a_loss, c_loss, c_data)
+    gen_evalmatch(y_metrics)
 
 
 if __name__ == "__main__":

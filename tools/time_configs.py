@@ -5,7 +5,9 @@
   dense   bs 32 x 100000 boxes x 80 classes, NMS(0.25, 0.45)       -- dense pre-NMS stress (top-30000 cut)
   sweep   16 images @1280 (100800 anchors), decode + NMS(0.001, 0.6, multi_label)  -- one GPU's share of the 1280 px sweep
 
-  python tools/time_configs.py [val,dense,sweep] [--iters 5]
+  match   bs 64 x 300 detections x <=40 labels: process_batches + ConfusionMatrix.process_batches (one launch each)
+
+  python tools/time_configs.py [val,dense,sweep,match] [--iters 5]
 """
 import argparse
 import math
@@ -43,7 +45,7 @@ def dense_pred(bs, A, nc, dev, seed=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", nargs="?", default="val,dense,sweep")
+    ap.add_argument("which", nargs="?", default="val,dense,sweep,match")
     ap.add_argument("--iters", type=int, default=5)
     args = ap.parse_args()
     which = set(args.which.split(","))
@@ -78,8 +80,38 @@ def main():
             levels.append(x)
         ms_d, z = wall(lambda: detect_decode(levels, anchors, strides), args.iters)
         ms_n, out = wall(lambda: non_max_suppression(z, 0.001, 0.6, multi_label=True), args.iters)
+        del levels, z
         print(f"sweep 16img@1280 decode {ms_d:8.3f} ms ({680.0 * 100800 * 16 / ms_d / 1e6:7.1f} GB/s)  NMS(0.001,0.6,ml) {ms_n:8.3f} ms  "
               f"({16 / (ms_d + ms_n) * 1e3:9.0f} img/s)  dets {sum(o.shape[0] for o in out)}", flush=True)
+    if "match" in which:
+        time_match(dev, args.iters)
+
+
+def time_match(dev, iters):
+    import numpy as np
+    from object_detection_amd.metrics import ConfusionMatrix
+    from object_detection_amd.val import process_batch, process_batches
+    rs = np.random.RandomState(1)
+    dets, labs = [], []
+    for _ in range(64):
+        m = int(rs.randint(1, 40))
+        c = rs.uniform(40, 600, (m, 2))
+        wh = np.exp(rs.uniform(np.log(12), np.log(200), (m, 2)))
+        lab = np.concatenate((rs.randint(0, 80, (m, 1)), c - wh / 2, c + wh / 2), 1).astype(np.float32)
+        src = rs.randint(0, m, 300)
+        det = np.zeros((300, 6), dtype=np.float32)
+        det[:, :4] = lab[src, 1:] + rs.normal(0, 0.07, (300, 4)) * np.tile(wh[src], 2)
+        det[:, 4] = np.sort(rs.uniform(0.001, 1, 300))[::-1]
+        det[:, 5] = lab[src, 0]
+        dets.append(torch.from_numpy(det).to(dev))
+        labs.append(torch.from_numpy(lab).to(dev))
+    iouv = torch.linspace(0.5, 0.95, 10).to(dev)
+    cm = ConfusionMatrix(nc=80)
+    ms_b, _ = wall(lambda: process_batches(dets, labs, iouv), iters)
+    ms_c, _ = wall(lambda: cm.process_batches(dets, labs), iters)
+    ms_1, _ = wall(lambda: [process_batch(d, t, iouv) for d, t in zip(dets, labs)], iters)
+    print(f"match bs64x300: process_batches {ms_b:7.3f} ms, ConfusionMatrix.process_batches {ms_c:7.3f} ms, "
+          f"64 x process_batch {ms_1:7.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
