@@ -90,6 +90,15 @@ int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int
                    double max_wh, int cap, float* out, int* out_span, int* cand_count, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* Fused inference path: the NMS of dh_nms_batched fed directly by the raw head maps of dh_yolo_decode (same level
+ * description), i.e. non_max_suppression(Detect(x)[0]) of object_detection/yolov5/val.py:194,203 and detect.py:126,132
+ * without materialising the decoded (bs, A, no) tensor: candidate rows are decoded on the fly with the arithmetic of
+ * dh_yolo_decode, so the output is bit-identical to the two-call sequence.  A = sum_l na*ny*nx; cap as in dh_nms_batched. */
+int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                       const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
+                       int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+                       float* out, int* out_span, int* cand_count, void* workspace, size_t workspace_bytes, void* stream);
+
 /* torchvision.ops.nms(boxes[n,4] xyxy, scores[n], iou_threshold) as called at
  * object_detection/yolov5/utils/general.py:722 and object_detection/detectors/centernet/dataset.py:263:
  * keep_index (n int64, device) receives the kept original indices in score-descending order

@@ -9,20 +9,10 @@
 #include <stdlib.h>
 
 #include "dh_common.h"
+#include "dh_decode.h"
 #include "../../include/dethead.h"
 
 namespace {
-
-struct decode_level {
-    const float* src;     // (bs, na, ny, nx, no) contiguous
-    uint32_t first;       // first output element of this level inside one image's span
-    uint32_t row_first;   // first output row (anchor) of this level inside one image
-    uint32_t elems;       // na*ny*nx*no
-    dh_fastdiv plane;     // ny*nx
-    dh_fastdiv nx;
-    float stride;
-    float anchor_px[2 * DH_MAX_ANCHORS];   // anchors[l][a] * stride[l]  (w,h)
-};
 
 struct decode_params {
     decode_level lvl[DH_MAX_LEVELS];
@@ -34,20 +24,6 @@ struct decode_params {
     float* obj_plane;     // optional (bs, A) copy of the objectness column, or nullptr
     float* logit_plane;   // optional (bs, A) copy of the raw objectness logit (input channel 4), or nullptr
 };
-
-// box channels (c < 4) of row `row`: xy = (2s - 0.5 + grid) * stride, wh = (2s)^2 * anchor_px
-__device__ __forceinline__ float decode_box(const decode_level& L, uint32_t row, uint32_t c, float s)
-{
-    const uint32_t a = dh_div(row, L.plane);
-    const uint32_t cell = row - a * L.plane.d;
-    const uint32_t gy = dh_div(cell, L.nx);
-    const uint32_t gx = cell - gy * L.nx.d;
-    const float g = (float)((c & 1u) ? gy : gx);
-    const float xy = (s * 2.0f - 0.5f + g) * L.stride;
-    const float t = s * 2.0f;
-    const float wh = (t * t) * L.anchor_px[2 * a + (c & 1u)];
-    return c < 2 ? xy : wh;
-}
 
 // One block owns DH_DEC_UNROLL*256 consecutive vectors of ONE level of ONE image, so the level
 // record is wave-uniform (scalar registers).  VEC = 4 needs every level span to be a multiple of
@@ -142,28 +118,10 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
     decode_params P;
     P.nl = nl;
     P.no = dh_make_fastdiv((uint32_t)no);
-    uint64_t first = 0;
-    uint32_t row_first = 0;
-    bool vec4 = dh_aligned16(out);
-    for (int l = 0; l < nl; ++l) {
-        if (!level_ptrs[l] || ny[l] < 1 || nx[l] < 1) return DH_ERR_ARG;
-        const uint64_t elems = (uint64_t)na * ny[l] * nx[l] * no;
-        if (first + elems >= (1ull << 31)) return DH_ERR_ARG;   // 32-bit element indices inside one image
-        decode_level& L = P.lvl[l];
-        L.src = level_ptrs[l];
-        L.first = (uint32_t)first;
-        L.row_first = row_first;
-        row_first += (uint32_t)(na * ny[l] * nx[l]);
-        L.elems = (uint32_t)elems;
-        L.plane = dh_make_fastdiv((uint32_t)(ny[l] * nx[l]));
-        L.nx = dh_make_fastdiv((uint32_t)nx[l]);
-        L.stride = strides[l];
-        for (int k = 0; k < 2 * na; ++k) L.anchor_px[k] = anchor_px[l * 2 * na + k];
-        vec4 = vec4 && (elems % 4 == 0) && dh_aligned16(level_ptrs[l]);
-        first += elems;
-    }
-    P.per_image = (uint32_t)first;
-    P.rows_per_image = row_first;
+    bool vec4 = false;
+    if (!dh_make_levels(level_ptrs, ny, nx, nl, na, no, anchor_px, strides, P.lvl, &P.per_image, &P.rows_per_image, &vec4))
+        return DH_ERR_ARG;
+    vec4 = vec4 && dh_aligned16(out);
     if (obj_logit_plane && !obj_plane) return DH_ERR_ARG;   // the logit copy rides on the objectness-plane path
     P.obj_plane = obj_plane;
     P.logit_plane = obj_logit_plane;

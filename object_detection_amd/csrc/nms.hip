@@ -24,6 +24,7 @@
 // Cross-class pairs are skipped only when the image's coordinate range proves they cannot intersect
 // after the 7680-px class offset; otherwise that image is handled as one segment with per-box offsets.
 #include "dh_common.h"
+#include "dh_decode.h"
 #include "../../include/dethead.h"
 
 namespace {
@@ -53,6 +54,34 @@ __device__ __forceinline__ float key_score(uint32_t k)
 
 __device__ __forceinline__ u64 lanemask_lt() { return (1ull << (threadIdx.x & 63)) - 1ull; }
 
+// Where the prediction rows come from: the decoded (bs, A, no) tensor, or (RAW) the head's raw maps, decoded on
+// the fly for the rows that need it -- the same arithmetic as the decode kernel, so both sources give the same bits,
+// and the decoded tensor never has to exist.
+struct nms_source {
+    const float* pred;
+    decode_level lvl[DH_MAX_LEVELS];
+    int nl, no;
+};
+
+struct raw_row {
+    const float* p;   // first element of the row inside its map
+    int l;            // level
+    uint32_t local;   // row index inside the level (anchor-major, then gy, gx)
+};
+
+__device__ __forceinline__ raw_row raw_row_of(const nms_source& S, int b, int row)
+{
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < DH_MAX_LEVELS; ++k)
+        if (k < S.nl && (uint32_t)row >= S.lvl[k].row_first) l = k;
+    raw_row r;
+    r.l = l;
+    r.local = (uint32_t)row - S.lvl[l].row_first;
+    r.p = S.lvl[l].src + (size_t)b * S.lvl[l].elems + (size_t)r.local * S.no;
+    return r;
+}
+
 // ------------------------------------------------------------------------------------------ 1 prefilter
 struct row_best {
     float v;
@@ -74,8 +103,8 @@ __device__ __forceinline__ row_best wave_argmax_first(float v, int c)
 // NCH > 0: the class scores of the rows in flight are fetched up front as NCH chunks of 64 classes
 // (nc <= 64*NCH), which keeps 4*NCH independent loads in flight per wave; NCH = 0 handles any nc
 // chunk by chunk.
-template <bool MULTI, int NCH>
-__global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__ pred, const float* __restrict__ obj_plane,
+template <bool MULTI, int NCH, bool RAW>
+__global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const float* __restrict__ obj_plane,
                                                        int A, int nc, float conf,
                                                        const unsigned char* __restrict__ class_keep, int cap,
                                                        u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
@@ -83,7 +112,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int no = nc + 5;
-    const float* __restrict__ img = pred + (size_t)b * A * no;
+    const float* __restrict__ img = RAW ? nullptr : S.pred + (size_t)b * A * no;
     u64* __restrict__ out = keys + (size_t)b * cap_pad;
     __shared__ u64 stage[4][STAGE_KEYS];
     int pending = 0;
@@ -91,7 +120,10 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__
     for (int row0 = (blockIdx.x * 4 + wave) * 64; row0 < A; row0 += gridDim.x * 256) {
         const int row = row0 + lane;
         float obj = 0.0f;
-        if (row < A) obj = obj_plane ? obj_plane[(size_t)b * A + row] : img[(size_t)row * no + 4];
+        if (row < A) {
+            if (RAW) obj = dh_sigmoid(raw_row_of(S, b, row).p[4]);
+            else obj = obj_plane ? obj_plane[(size_t)b * A + row] : img[(size_t)row * no + 4];
+        }
         const bool cand = (row < A) && (obj > conf);                       // general.py:656,675
         u64 todo = __ballot(cand);
         float my_best = 0.0f;
@@ -114,15 +146,20 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__
             }
             float bv[4];
             int bc[4];
+            const float* rp[4];      // first class score of each row in flight (wave-uniform)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { bv[k] = -INFINITY; bc[k] = 0x7fffffff; }
+            for (int k = 0; k < 4; ++k) {
+                bv[k] = -INFINITY;
+                bc[k] = 0x7fffffff;
+                rp[k] = (RAW ? raw_row_of(S, b, row0 + r[k]).p : img + (size_t)(row0 + r[k]) * no) + 5;
+            }
             float pre[4][NCH > 0 ? NCH : 1];
             if (NCH > 0) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int h = 0; h < NCH; ++h)
-                        pre[k][h] = (h * 64 + lane < nc) ? img[(size_t)(row0 + r[k]) * no + 5 + h * 64 + lane] : 0.0f;
+                        pre[k][h] = (h * 64 + lane < nc) ? rp[k][h * 64 + lane] : 0.0f;
             }
             const int nch = NCH > 0 ? NCH : (nc + 63) / 64;
 #pragma unroll
@@ -132,7 +169,8 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const float* __restrict__
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (NCH > 0) v[k] = pre[k][NCH > 0 ? h : 0];
-                    else v[k] = (c < nc) ? img[(size_t)(row0 + r[k]) * no + 5 + c] : 0.0f;
+                    else v[k] = (c < nc) ? rp[k][c] : 0.0f;
+                    if (RAW) v[k] = dh_sigmoid(v[k]);          // yolo.py:62
                 }
                 const bool keepc = (c < nc) && (class_keep == nullptr || class_keep[c] != 0);   // general.py:705-706
 #pragma unroll
@@ -342,7 +380,8 @@ struct img_range {   // per image: coordinate range of the boxes that reach NMS 
     int bad, pad;
 };
 
-__global__ void __launch_bounds__(256) k_nms_gather(const float* __restrict__ pred, int A, dh_fastdiv ncd,
+template <bool RAW>
+__global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, dh_fastdiv ncd,
                                                     const u64* __restrict__ keys, int cap_pad,
                                                     const int* __restrict__ counts, int cap, int max_nms,
                                                     float* __restrict__ det, u64* __restrict__ keys2, int m_pad,
@@ -361,8 +400,18 @@ __global__ void __launch_bounds__(256) k_nms_gather(const float* __restrict__ pr
         const uint32_t ord = (uint32_t)key;
         const uint32_t anchor = dh_div(ord, ncd);
         const uint32_t cls = ord - anchor * ncd.d;
-        const float* __restrict__ p = pred + ((size_t)b * A + anchor) * no;
-        const float x = p[0], y = p[1], w = p[2], h = p[3];
+        float x, y, w, h;
+        if (RAW) {
+            const raw_row rr = raw_row_of(S, b, (int)anchor);
+            const decode_level& L = S.lvl[rr.l];
+            x = decode_box(L, rr.local, 0, dh_sigmoid(rr.p[0]));
+            y = decode_box(L, rr.local, 1, dh_sigmoid(rr.p[1]));
+            w = decode_box(L, rr.local, 2, dh_sigmoid(rr.p[2]));
+            h = decode_box(L, rr.local, 3, dh_sigmoid(rr.p[3]));
+        } else {
+            const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
+            x = p[0]; y = p[1]; w = p[2]; h = p[3];
+        }
         const float x1 = x - w / 2, y1 = y - h / 2, x2 = x + w / 2, y2 = y + h / 2;     // general.py:553-560
         float* __restrict__ d = det + ((size_t)b * m_cap + r) * 6;
         d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2;
@@ -672,15 +721,16 @@ extern "C" size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms)
     return make_layout(bs, cap, max_nms, nc).total;
 }
 
-extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
-                              int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
-                              int max_nms, double max_wh, int cap, float* out, int* out_span, int* cand_count,
-                              void* workspace, size_t workspace_bytes, void* stream)
+namespace {
+
+int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
+            int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+            float* out, int* out_span, int* cand_count, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (bs < 0 || bs > 65535 || A < 1 || nc < 1 || max_det < 1 || max_nms < 1 || cap < 1) return DH_ERR_ARG;
     if ((long long)A * nc >= (1ll << 32)) return DH_ERR_ARG;
     if (bs == 0) return DH_OK;
-    if (!pred || !out || !out_span || !cand_count || !workspace) return DH_ERR_ARG;
+    if (!out || !out_span || !cand_count || !workspace) return DH_ERR_ARG;
     const nms_layout L = make_layout(bs, cap, max_nms, nc);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
@@ -702,16 +752,20 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
     int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks
     const int gx_cap = 8192 / bs > 1 ? 8192 / bs : 1;
     if (gx > gx_cap) gx = gx_cap;
-#define DH_PREFILTER(M, N) hipLaunchKernelGGL((k_nms_prefilter<M, N>), dim3(gx, bs), dim3(256), 0, st, pred, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
-    if (multi_label) {
-        if (nc <= 64) DH_PREFILTER(true, 1); else if (nc <= 128) DH_PREFILTER(true, 2); else DH_PREFILTER(true, 0);
-    } else {
-        if (nc <= 64) DH_PREFILTER(false, 1); else if (nc <= 128) DH_PREFILTER(false, 2); else DH_PREFILTER(false, 0);
-    }
+#define DH_PREFILTER(M, N, R) hipLaunchKernelGGL((k_nms_prefilter<M, N, R>), dim3(gx, bs), dim3(256), 0, st, S, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
+#define DH_PREFILTER_N(M, R) do { if (nc <= 64) DH_PREFILTER(M, 1, R); else if (nc <= 128) DH_PREFILTER(M, 2, R); else DH_PREFILTER(M, 0, R); } while (0)
+    if (multi_label) { if (raw) DH_PREFILTER_N(true, true); else DH_PREFILTER_N(true, false); }
+    else { if (raw) DH_PREFILTER_N(false, true); else DH_PREFILTER_N(false, false); }
+#undef DH_PREFILTER_N
 #undef DH_PREFILTER
     hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys, counts, cap, L.cap_pad, (int2*)nullptr, 0);
-    hipLaunchKernelGGL(k_nms_gather, dim3((L.m_cap + 255) / 256, bs), dim3(256), 0, st, pred, A, dh_make_fastdiv((uint32_t)nc),
-                       keys, L.cap_pad, counts, cap, max_nms, det, keys2, L.m_pad, L.m_cap, range);
+    const dim3 ggrid((L.m_cap + 255) / 256, bs);
+    if (raw)
+        hipLaunchKernelGGL(k_nms_gather<true>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad,
+                           counts, cap, max_nms, det, keys2, L.m_pad, L.m_cap, range);
+    else
+        hipLaunchKernelGGL(k_nms_gather<false>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad,
+                           counts, cap, max_nms, det, keys2, L.m_pad, L.m_cap, range);
     if (!agnostic) {
         // keys2 holds m = min(n, max_nms) entries per image; k_sort_keys clamps to `limit`
         hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys2, counts, L.m_cap, L.m_pad, seg, nc);
@@ -724,6 +778,40 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
     hipLaunchKernelGGL(k_nms_collect, dim3(bs), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, cap, max_nms,
                        max_det, out, (long long*)nullptr, (int*)nullptr, cursor, (int2*)out_span, cand_count);
     return dh_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
+                              int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
+                              int max_nms, double max_wh, int cap, float* out, int* out_span, int* cand_count,
+                              void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (bs > 0 && !pred) return DH_ERR_ARG;
+    nms_source S;
+    S.pred = pred;
+    S.nl = 0;
+    S.no = nc + 5;
+    return nms_run(S, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
+                   max_wh, cap, out, out_span, cand_count, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                                  const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
+                                  int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
+                                  double max_wh, int cap, float* out, int* out_span, int* cand_count, void* workspace,
+                                  size_t workspace_bytes, void* stream)
+{
+    if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 6) return DH_ERR_ARG;
+    if (!level_ptrs || !ny || !nx || !anchor_px || !strides) return DH_ERR_ARG;
+    nms_source S;
+    S.pred = nullptr;
+    S.nl = nl;
+    S.no = no;
+    uint32_t per_image = 0, rows = 0;
+    if (!dh_make_levels(level_ptrs, ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image, &rows, nullptr)) return DH_ERR_ARG;
+    return nms_run(S, true, nullptr, bs, (int)rows, no - 5, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det,
+                   max_nms, max_wh, cap, out, out_span, cand_count, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t dh_nms_plain_workspace(int64_t n)

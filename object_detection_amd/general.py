@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .yolo import objectness_plane
+from .yolo import _anchor_pixels, objectness_plane
 
 MAX_WH = 7680      # general.py:663
 MAX_NMS = 30000    # general.py:664
@@ -121,13 +121,7 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     max_det = int(max_det)
     if bs == 0 or A == 0 or max_det < 1:
         return None, None, 0
-    keep_mask = None
-    if classes is not None:
-        flags = torch.zeros(nc, dtype=torch.uint8)
-        idx = [int(c) for c in classes if float(c) == int(c) and 0 <= int(c) < nc]
-        if idx:
-            flags[idx] = 1
-        keep_mask = flags.to(dev)
+    keep_mask = _class_keep(classes, nc, dev)
     lib = L.lib()
     cap = A if cap is None else int(cap)
     rows = torch.empty((bs * max_det, 6), dtype=torch.float32, device=dev)
@@ -140,6 +134,73 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
                                    L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs), L.ptr(ws),
                                    ws_bytes, L.stream()), "dh_nms_batched")
     return rows, meta, cap
+
+
+def _class_keep(classes, nc, dev):
+    if classes is None:
+        return None
+    flags = torch.zeros(nc, dtype=torch.uint8)
+    idx = [int(c) for c in classes if float(c) == int(c) and 0 <= int(c) < nc]
+    if idx:
+        flags[idx] = 1
+    return flags.to(dev)
+
+
+def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
+                      multi_label=False, max_det=300, cap=None):
+    """nms_launch fed by the raw head maps: the same (rows, meta, cap) as
+    nms_launch(detect_decode(levels, anchors, stride), ...), without writing or reading the decoded tensor."""
+    assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
+    assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
+    xs = [L.dev_f32(x, f"x[{i}]").contiguous() for i, x in enumerate(levels)]
+    nl = len(xs)
+    bs, na, _, _, no = xs[0].shape
+    for x in xs:
+        if x.dim() != 5 or x.shape[0] != bs or x.shape[1] != na or x.shape[4] != no:
+            raise RuntimeError(f"detect_nms: inconsistent level shape {tuple(x.shape)}")
+    if no < 6:
+        raise RuntimeError(f"detect_nms: maps must have 5+nc channels with nc >= 1, got {no}")
+    nc = no - 5
+    ny = [int(x.shape[2]) for x in xs]
+    nx = [int(x.shape[3]) for x in xs]
+    A = sum(na * a * b for a, b in zip(ny, nx))
+    dev = xs[0].device
+    max_det = int(max_det)
+    if bs == 0 or A == 0 or max_det < 1:
+        return None, None, 0
+    multi_label = bool(multi_label) and nc > 1
+    keep_mask = _class_keep(classes, nc, dev)
+    anchor_px, strides = _anchor_pixels(anchors, stride)
+    lib = L.lib()
+    cap = A if cap is None else int(cap)
+    rows = torch.empty((bs * max_det, 6), dtype=torch.float32, device=dev)
+    meta = torch.empty(3 * bs, dtype=torch.int32, device=dev)
+    ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
+    ws = L.workspace(ws_bytes, dev)
+    ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
+    with L.device_guard(dev):
+        L.check(lib.dh_yolo_decode_nms(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
+                                       float(conf_thres), float(iou_thres), int(multi_label), int(bool(agnostic)),
+                                       L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, L.ptr(rows), L.ptr(meta),
+                                       L.c_void_p(meta.data_ptr() + 8 * bs), L.ptr(ws), ws_bytes, L.stream()),
+                "dh_yolo_decode_nms")
+    return rows, meta, cap
+
+
+def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+               max_det=300):
+    """non_max_suppression(Detect(x)[0], ...) (val.py:194,203; detect.py:126,132) straight from the raw head maps
+    `levels` (list of (bs,na,ny,nx,5+nc)); anchors / stride as Detect holds them.  Bit-identical to the two-call
+    sequence, at about half its HBM traffic: the decoded (bs, A, 5+nc) tensor is neither written nor read."""
+    cap = None
+    while True:
+        rows, meta, cap = detect_nms_launch(levels, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
+                                            max_det, cap)
+        if rows is None:
+            return [torch.zeros((0, 6), device=levels[0].device)] * levels[0].shape[0]
+        result, cap = nms_finish(rows, meta, cap)
+        if result is not None:
+            return result
 
 
 def nms_meta_to_host(meta, pinned=None):

@@ -22,7 +22,7 @@ def T(a):
 def same_lists(got, want):
     assert [int(d.shape[0]) for d in got] == [int(w.shape[0]) for w in want]
     for d, w in zip(got, want):
-        w = w.numpy() if isinstance(w, torch.Tensor) else w
+        w = w.cpu().numpy() if isinstance(w, torch.Tensor) else w
         np.testing.assert_array_equal(d.cpu().numpy(), w)
 
 
@@ -184,3 +184,35 @@ def test_nms_uses_decode_objectness_plane_only_while_valid():
     z[:, :, 4] *= 0.5                                   # in-place edit: the side copy is stale now
     assert objectness_plane(z) is None
     same_lists(non_max_suppression(z, 0.25, 0.45), [w.cpu() for w in non_max_suppression(z.clone(), 0.25, 0.45)])
+
+
+@pytest.mark.parametrize("kw", [dict(conf_thres=0.25, iou_thres=0.45), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+                                dict(conf_thres=0.05, iou_thres=0.5, agnostic=True, max_det=1000),
+                                dict(conf_thres=0.02, iou_thres=0.3, multi_label=True, classes=[1, 3, 5, 79], max_det=50)])
+def test_fused_decode_nms_equals_two_calls_and_oracle(kw):
+    """detect_nms(raw maps) == non_max_suppression(detect_decode(raw maps)) bit for bit, and == the oracle run on the
+    HIP-decoded tensor; rectangular levels, batch 5."""
+    from object_detection_amd.general import detect_nms, non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    from oracle import yolo as oy
+    from tests._synth import synth_head, synth_targets
+    rs = np.random.RandomState(31)
+    bs, nc = 5, 80
+    levels = [x[:, :, : x.shape[2] * 3 // 4] for x in synth_head(rs, bs, 320, nc)]       # ny != nx
+    levels = [np.ascontiguousarray(x) for x in levels]
+    anchors = oy.grid_anchors()
+    crit = oy.YoloLossOracle(anchors, dict(oy.HYP_SCRATCH), nc=nc)
+    targets = synth_targets(rs, 60, bs)
+    targets[:, 3] *= 0.7
+    for l, t in enumerate(crit.targets_for([T(x) for x in levels], T(targets))):
+        levels[l][t["b"], t["a"], t["gj"], t["gi"], 4] = 1.5 + rs.normal(0, 1, len(t["b"]))
+        levels[l][t["b"], t["a"], t["gj"], t["gi"], 5 + t["tcls"]] = 2.0 + rs.normal(0, 1, len(t["b"]))
+        levels[l][t["b"], t["a"], t["gj"], t["gi"], 0:4] *= 0.3
+    dev = [T(x).cuda() for x in levels]
+    strides = torch.tensor(oy.YOLOV5S_STRIDES)
+    z = detect_decode(dev, anchors.cuda(), strides)
+    two = non_max_suppression(z, **kw)
+    fused = detect_nms(dev, anchors.cuda(), strides, **kw)
+    same_lists(fused, two)
+    same_lists(fused, onms.non_max_suppression(z.cpu().clone(), **kw))
+    assert sum(t.shape[0] for t in two) > 20

@@ -50,7 +50,7 @@ def main():
     args = ap.parse_args()
     which = set(args.which.split(","))
     dev = torch.device("cuda", 0)
-    from object_detection_amd.general import non_max_suppression
+    from object_detection_amd.general import detect_nms, non_max_suppression
     from object_detection_amd.yolo import detect_decode
     from object_detection_amd.yolo_loss import ComputeLoss
     anchors = bench.grid_anchors(dev)
@@ -63,6 +63,10 @@ def main():
         z = detect_decode(levels, anchors, strides)
         ms, out = wall(lambda: non_max_suppression(z, 0.001, 0.6, multi_label=True), args.iters)
         print(f"val   bs64@640 NMS(0.001,0.6,multi_label): {ms:8.3f} ms  ({64 / ms * 1e3:9.0f} img/s)  dets {sum(o.shape[0] for o in out)}", flush=True)
+        for kw, name in ((dict(conf_thres=0.25, iou_thres=0.45), "0.25,0.45"), (dict(conf_thres=0.001, iou_thres=0.6, multi_label=True), "0.001,0.6,ml")):
+            ms2, _ = wall(lambda: non_max_suppression(detect_decode(levels, anchors, strides), **kw), args.iters)
+            ms1, _ = wall(lambda: detect_nms(levels, anchors, strides, **kw), args.iters)
+            print(f"val   bs64@640 decode + NMS({name}): two calls {ms2:8.3f} ms, fused detect_nms {ms1:8.3f} ms", flush=True)
         del levels, z
     if "dense" in which:
         pred = dense_pred(32, 100000, 80, dev)
@@ -80,7 +84,9 @@ def main():
             levels.append(x)
         ms_d, z = wall(lambda: detect_decode(levels, anchors, strides), args.iters)
         ms_n, out = wall(lambda: non_max_suppression(z, 0.001, 0.6, multi_label=True), args.iters)
+        ms_f, _ = wall(lambda: detect_nms(levels, anchors, strides, 0.001, 0.6, multi_label=True), args.iters)
         del levels, z
+        print(f"sweep 16img@1280 fused detect_nms {ms_f:8.3f} ms ({16 / ms_f * 1e3:9.0f} img/s)", flush=True)
         print(f"sweep 16img@1280 decode {ms_d:8.3f} ms ({680.0 * 100800 * 16 / ms_d / 1e6:7.1f} GB/s)  NMS(0.001,0.6,ml) {ms_n:8.3f} ms  "
               f"({16 / (ms_d + ms_n) * 1e3:9.0f} img/s)  dets {sum(o.shape[0] for o in out)}", flush=True)
     if "match" in which:
