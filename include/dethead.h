@@ -82,13 +82,18 @@ int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx,
  * multi_label; cap = A always suffices otherwise).
  * class_keep: nc bytes on the device (1 = keep class) or NULL (general.py:705-706).
  * obj_plane: NULL, or (bs, A) floats holding exactly pred[:, :, 4] (see dh_yolo_decode).
- * max_nms = 30000 and max_wh = 7680 in the reference (general.py:663-664).  All of out, out_span,
- * cand_count, workspace are device memory; workspace must be 256-byte aligned. */
+ * max_nms = 30000 and max_wh = 7680 in the reference (general.py:663-664).
+ * k_select: 0 = every candidate is sorted and goes through NMS.  > 0 = only the k_select best-scoring candidates
+ * of an image (rounded up so that at least 8*max_det fit; ignored when that exceeds the 16384-key LDS sorter) do:
+ * the output is the first max_det kept rows in score order and a row's fate depends only on rows ranked above
+ * it, so the result is exact whenever that prefix yields max_det rows.  needs_full[b] = 1 marks the images where it
+ * did not (their output rows are incomplete): repeat the call with k_select = 0.  With k_select = 0 needs_full is all 0.
+ * All of out, out_span, cand_count, needs_full (bs ints), workspace are device memory; workspace must be 256-byte aligned. */
 size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms);
 int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
                    int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
-                   double max_wh, int cap, float* out, int* out_span, int* cand_count, void* workspace,
-                   size_t workspace_bytes, void* stream);
+                   double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count, int* needs_full,
+                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused inference path: the NMS of dh_nms_batched fed directly by the raw head maps of dh_yolo_decode (same level
  * description), i.e. non_max_suppression(Detect(x)[0]) of object_detection/yolov5/val.py:194,203 and detect.py:126,132
@@ -97,7 +102,8 @@ int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int
 int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
                        const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
                        int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
-                       float* out, int* out_span, int* cand_count, void* workspace, size_t workspace_bytes, void* stream);
+                       int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* torchvision.ops.nms(boxes[n,4] xyxy, scores[n], iou_threshold) as called at
  * object_detection/yolov5/utils/general.py:722 and object_detection/detectors/centernet/dataset.py:263:

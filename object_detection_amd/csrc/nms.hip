@@ -308,14 +308,17 @@ __device__ void write_segments(const u64* k, int n, int2* __restrict__ seg)
 
 // One workgroup sorts one image's keys ascending.  n = min(counts[b], limit).
 // seg_all != nullptr: the keys are [class | rank]; also record each class's [begin, end) (zero-initialised by the caller).
+// m_out != nullptr: also record how many of the sorted keys go on to NMS, min(n, max_nms) (general.py:716-717).
 __global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ keys_all, const int* __restrict__ counts,
-                                                            int limit, int cap_pad, int2* __restrict__ seg_all, int nc)
+                                                            int limit, int cap_pad, int2* __restrict__ seg_all, int nc,
+                                                            int* __restrict__ m_out, int max_nms)
 {
     __shared__ u64 s[SORT_LDS_KEYS];
     u64* __restrict__ keys = keys_all + (size_t)blockIdx.x * cap_pad;
     int2* __restrict__ seg = seg_all ? seg_all + (size_t)blockIdx.x * nc : nullptr;
     int n = counts[blockIdx.x];
     if (n > limit) n = limit;
+    if (m_out && threadIdx.x == 0) m_out[blockIdx.x] = n < max_nms ? (n > 0 ? n : 0) : max_nms;
     if (n <= 0) return;
     if (n == 1) {
         if (seg && threadIdx.x == 0) { const uint32_t c = (uint32_t)(keys[0] >> 32); seg[c].x = 0; seg[c].y = 1; }
@@ -362,6 +365,102 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ ke
     if (seg) write_segments(keys, n, seg);
 }
 
+// ------------------------------------------------------------------------------------------ 2' select + sort
+// Only the rows that can reach the output need to go through NMS: the output is the first max_det kept rows in score
+// order, and whether a row is kept depends only on rows that rank above it.  So NMS on a score-ordered prefix is
+// exact for that prefix, and if the prefix yields max_det kept rows nothing below it matters.  This kernel picks
+// the prefix: the k_target best keys of the image plus everything that shares the 22-bit score prefix of the last
+// one (two rounds of an 11-bit radix select in LDS), sorted.  k_nms_collect reports the images whose prefix did not
+// yield max_det rows (needs_full); the caller repeats those batches with the full sort.
+#define SELECT_BINS 2048
+
+__global__ void __launch_bounds__(SORT_THREADS) k_select_sort(const u64* __restrict__ keys_all, const int* __restrict__ counts,
+                                                              int limit, int cap_pad, int k_target, int max_nms,
+                                                              u64* __restrict__ top_all, int top_pad,
+                                                              int* __restrict__ m_out, int* __restrict__ truncated)
+{
+    __shared__ u64 s[SORT_LDS_KEYS];
+    __shared__ int hist[SELECT_BINS];
+    __shared__ int wsum[SORT_THREADS / 64];
+    __shared__ int s_bin, s_below, s_count, s_fill;
+    const u64* __restrict__ keys = keys_all + (size_t)blockIdx.x * cap_pad;
+    u64* __restrict__ top = top_all + (size_t)blockIdx.x * top_pad;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int n = counts[blockIdx.x];
+    if (n > limit) n = limit;
+    if (n <= 0) {
+        if (threadIdx.x == 0) { m_out[blockIdx.x] = 0; truncated[blockIdx.x] = 0; }
+        return;
+    }
+    const int n_lim = n < max_nms ? n : max_nms;
+    int T = n;
+    if (n > k_target) {
+        uint32_t prefix = 0;
+        int below = 0;
+        for (int round = 0; round < 2; ++round) {
+            const int shift = round == 0 ? 53 : 42;
+            for (int i = threadIdx.x; i < SELECT_BINS; i += SORT_THREADS) hist[i] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += SORT_THREADS) {
+                const u64 key = keys[i];
+                if (round == 0 || (uint32_t)(key >> 53) == prefix) atomicAdd(&hist[(uint32_t)(key >> shift) & (SELECT_BINS - 1)], 1);
+            }
+            __syncthreads();
+            // the bin that holds the (k_target - below)-th key of this round: block-wide inclusive scan, 2 bins per thread
+            const int c0 = hist[2 * threadIdx.x], c1 = hist[2 * threadIdx.x + 1];
+            int incl = c0 + c1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += v;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < wave; ++w) base += wsum[w];
+            incl += base;
+            const int excl = incl - (c0 + c1);
+            const int need = k_target - below;
+            if (excl < need && need <= excl + c0) { s_bin = 2 * threadIdx.x; s_below = below + excl; s_count = c0; }
+            else if (excl + c0 < need && need <= incl) { s_bin = 2 * threadIdx.x + 1; s_below = below + excl + c0; s_count = c1; }
+            __syncthreads();
+            prefix = round == 0 ? (uint32_t)s_bin : ((prefix << 11) | (uint32_t)s_bin);
+            below = s_below;
+            T = s_below + s_count;
+            __syncthreads();
+        }
+        if (T > SORT_LDS_KEYS) {      // too many keys share one 22-bit score prefix: leave this image to the full path
+            if (threadIdx.x == 0) { m_out[blockIdx.x] = 0; truncated[blockIdx.x] = 1; }
+            return;
+        }
+        if (threadIdx.x == 0) s_fill = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < n; i0 += SORT_THREADS) {
+            const int i = i0 + threadIdx.x;
+            u64 key = 0;
+            bool take = false;
+            if (i < n) { key = keys[i]; take = (uint32_t)(key >> 42) <= prefix; }
+            const u64 bm = __ballot(take);
+            int slot = 0;
+            if (lane == 0 && bm) slot = atomicAdd(&s_fill, __popcll(bm));
+            slot = __shfl(slot, 0, 64) + __popcll(bm & lanemask_lt());
+            if (take) s[slot] = key;
+        }
+        __syncthreads();
+    } else {
+        for (int i = threadIdx.x; i < n; i += SORT_THREADS) s[i] = keys[i];
+    }
+    const uint32_t npad = pow2_ceil((uint32_t)(T < 2 ? 2 : T));
+    for (uint32_t i = T + threadIdx.x; i < npad; i += SORT_THREADS) s[i] = KEY_SENTINEL;
+    __syncthreads();
+    bitonic_lds(s, npad, 0, 2, npad);
+    for (int i = threadIdx.x; i < T; i += SORT_THREADS) top[i] = s[i];
+    if (threadIdx.x == 0) {
+        m_out[blockIdx.x] = T < max_nms ? T : max_nms;
+        truncated[blockIdx.x] = T < n_lim ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 3 gather
 // monotone float <-> uint32 (ascending); both range words below are kept with atomicMax so that an
 // all-zero workspace is their valid initial state: hi_key = max key(hi), lo_inv = max ~key(lo)
@@ -383,14 +482,12 @@ struct img_range {   // per image: coordinate range of the boxes that reach NMS 
 template <bool RAW>
 __global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, dh_fastdiv ncd,
                                                     const u64* __restrict__ keys, int cap_pad,
-                                                    const int* __restrict__ counts, int cap, int max_nms,
+                                                    const int* __restrict__ m_arr,
                                                     float* __restrict__ det, u64* __restrict__ keys2, int m_pad,
                                                     int m_cap, img_range* __restrict__ range)
 {
     const int b = blockIdx.y;
-    int n = counts[b];
-    if (n > cap) n = cap;
-    const int m = n < max_nms ? n : max_nms;                                        // general.py:716-717
+    const int m = m_arr[b];                                                         // rows that go on to NMS
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const int no = (int)ncd.d + 5;
     float lo = INFINITY, hi = -INFINITY;
@@ -472,16 +569,14 @@ __device__ __forceinline__ bool suppresses(const box_t a, float area_a, const bo
 //   block (0, b) owns ranks 0..m-1 in rank order, each box shifted by its own class offset.
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restrict__ det, const u64* __restrict__ keys2,
-                                                           int m_pad, int m_cap, const int* __restrict__ counts,
-                                                           int cap, int max_nms, const img_range* __restrict__ range,
+                                                           int m_pad, int m_cap, const int* __restrict__ m_arr,
+                                                           const img_range* __restrict__ range,
                                                            const int2* __restrict__ seg_all, int agnostic, float max_wh,
                                                            float thr, int max_det,
                                                            unsigned char* __restrict__ keep, float4* __restrict__ kept_spill)
 {
     const int b = blockIdx.y;
-    int n = counts[b];
-    if (n > cap) n = cap;
-    const int m = n < max_nms ? n : max_nms;
+    const int m = m_arr[b];
     if (m == 0) return;
     bool whole = agnostic != 0;
     if (!whole) {
@@ -587,16 +682,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
 // (cursor == nullptr: single image, base 0.)
 __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ det, const unsigned char* __restrict__ keep,
                                                       const u64* __restrict__ keys, int cap_pad, int m_cap,
-                                                      const int* __restrict__ counts, int cap, int max_nms, int max_det,
+                                                      const int* __restrict__ counts, const int* __restrict__ m_arr,
+                                                      const int* __restrict__ truncated, int max_det,
                                                       float* __restrict__ out, long long* __restrict__ out_index,
                                                       int* __restrict__ out_count, int* __restrict__ cursor,
-                                                      int2* __restrict__ out_span, int* __restrict__ cand_count)
+                                                      int2* __restrict__ out_span, int* __restrict__ cand_count,
+                                                      int* __restrict__ needs_full)
 {
     const int b = blockIdx.x;
-    int n = counts[b];
-    if (cand_count && threadIdx.x == 0) cand_count[b] = n;
-    if (n > cap) n = cap;
-    const int m = n < max_nms ? n : max_nms;
+    if (cand_count && threadIdx.x == 0) cand_count[b] = counts[b];
+    const int m = m_arr[b];
     __shared__ int wcount[16];
     __shared__ int s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -612,6 +707,9 @@ __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ 
         for (int w = 0; w < 16; ++w) total += wcount[w];
         __syncthreads();
     }
+    // Only a score-ordered prefix went through NMS (truncated): its kept rows are the final answer iff there are
+    // max_det of them, because rows beyond the prefix rank below every one of these.
+    if (needs_full && threadIdx.x == 0) needs_full[b] = (truncated && truncated[b] && total < max_det) ? 1 : 0;
     if (total > max_det) total = max_det;
     if (threadIdx.x == 0) {
         const int first = cursor ? atomicAdd(cursor, total) : 0;
@@ -649,11 +747,11 @@ __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ 
 
 // plain nms(): keys from scores, det rows from boxes
 __global__ void __launch_bounds__(256) k_nms_plain_keys(const float* __restrict__ scores, int n, u64* __restrict__ keys,
-                                                        int* __restrict__ counts)
+                                                        int* __restrict__ counts, int* __restrict__ m_arr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) keys[i] = ((u64)score_key(scores[i]) << 32) | (uint32_t)i;
-    if (i == 0) counts[0] = n;
+    if (i == 0) { counts[0] = n; m_arr[0] = n; }
 }
 
 __global__ void __launch_bounds__(256) k_nms_plain_gather(const float* __restrict__ boxes, const u64* __restrict__ keys,
@@ -671,7 +769,8 @@ __global__ void __launch_bounds__(256) k_nms_plain_gather(const float* __restric
 
 struct nms_layout {
     int cap_pad, m_cap, m_pad;
-    size_t off_counts, off_range, off_cursor, off_seg, off_keys, off_keys2, off_det, off_keep, off_spill, total;
+    size_t off_counts, off_m, off_trunc, off_range, off_cursor, off_seg, off_keys, off_top, off_keys2, off_det, off_keep, off_spill, total;
+    int top_pad;         // keys per image in the select-sort output (0: selection not used)
     size_t zero_bytes;   // [0, zero_bytes) = counts, ranges, cursor, segment table, keep flags: cleared by one memset
 };
 
@@ -684,7 +783,18 @@ uint32_t pow2_ceil_host(uint32_t n)
     return p;
 }
 
-nms_layout make_layout(int bs, int cap, int max_nms, int nc)
+// smallest selection target >= k_select that leaves room for 8*max_det rows; 0 when that does not fit the LDS sorter
+int select_target(int k_select, int max_det, int cap, int max_nms)
+{
+    if (k_select <= 0) return 0;
+    long k = k_select;
+    while (k < 8l * max_det) k = 2 * (k + 256) - 256;
+    if (k > SORT_LDS_KEYS - 256) return 0;
+    const int all = cap < max_nms ? cap : max_nms;
+    return k < all ? (int)k : 0;          // nothing to cut when every candidate fits anyway
+}
+
+nms_layout make_layout(int bs, int cap, int max_nms, int nc, bool with_top = true)
 {
     nms_layout L;
     L.cap_pad = (int)pow2_ceil_host((uint32_t)(cap < 2 ? 2 : cap));
@@ -693,12 +803,16 @@ nms_layout make_layout(int bs, int cap, int max_nms, int nc)
     L.m_pad = (int)pow2_ceil_host((uint32_t)(L.m_cap < 2 ? 2 : L.m_cap));
     size_t o = 0;
     L.off_counts = o; o = align_up(o + sizeof(int) * bs, 256);
+    L.off_m = o; o = align_up(o + sizeof(int) * bs, 256);
+    L.off_trunc = o; o = align_up(o + sizeof(int) * bs, 256);
     L.off_range = o; o = align_up(o + sizeof(img_range) * bs, 256);
     L.off_cursor = o; o = align_up(o + sizeof(int), 256);
     L.off_seg = o; o = align_up(o + sizeof(int2) * (size_t)bs * nc, 256);
     L.off_keep = o; o = align_up(o + (size_t)bs * L.m_cap, 256);
     L.zero_bytes = o;
     L.off_keys = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.cap_pad, 256);
+    L.top_pad = with_top ? SORT_LDS_KEYS : 0;
+    L.off_top = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.top_pad, 256);
     L.off_keys2 = o; o = align_up(o + sizeof(u64) * (size_t)bs * L.m_pad, 256);
     L.off_det = o; o = align_up(o + sizeof(float) * 6 * (size_t)bs * L.m_cap, 256);
     L.off_spill = o; o = align_up(o + sizeof(float4) * (size_t)bs * L.m_cap, 256);
@@ -725,17 +839,21 @@ namespace {
 
 int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
             int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
-            float* out, int* out_span, int* cand_count, void* workspace, size_t workspace_bytes, void* stream)
+            int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+            size_t workspace_bytes, void* stream)
 {
     if (bs < 0 || bs > 65535 || A < 1 || nc < 1 || max_det < 1 || max_nms < 1 || cap < 1) return DH_ERR_ARG;
     if ((long long)A * nc >= (1ll << 32)) return DH_ERR_ARG;
     if (bs == 0) return DH_OK;
-    if (!out || !out_span || !cand_count || !workspace) return DH_ERR_ARG;
+    if (!out || !out_span || !cand_count || !needs_full || !workspace) return DH_ERR_ARG;
     const nms_layout L = make_layout(bs, cap, max_nms, nc);
+    const int k_target = select_target(k_select, max_det, cap, max_nms);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
     int* counts = (int*)(ws + L.off_counts);
+    int* m_arr = (int*)(ws + L.off_m);
+    int* truncated = (int*)(ws + L.off_trunc);
     img_range* range = (img_range*)(ws + L.off_range);
     int2* seg = (int2*)(ws + L.off_seg);
     unsigned char* keep = (unsigned char*)(ws + L.off_keep);
@@ -758,25 +876,38 @@ int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A
     else { if (raw) DH_PREFILTER_N(false, true); else DH_PREFILTER_N(false, false); }
 #undef DH_PREFILTER_N
 #undef DH_PREFILTER
-    hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys, counts, cap, L.cap_pad, (int2*)nullptr, 0);
-    const dim3 ggrid((L.m_cap + 255) / 256, bs);
-    if (raw)
-        hipLaunchKernelGGL(k_nms_gather<true>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad,
-                           counts, cap, max_nms, det, keys2, L.m_pad, L.m_cap, range);
-    else
-        hipLaunchKernelGGL(k_nms_gather<false>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad,
-                           counts, cap, max_nms, det, keys2, L.m_pad, L.m_cap, range);
-    if (!agnostic) {
-        // keys2 holds m = min(n, max_nms) entries per image; k_sort_keys clamps to `limit`
-        hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys2, counts, L.m_cap, L.m_pad, seg, nc);
-        hipLaunchKernelGGL(k_nms_greedy<4>, dim3(nc, bs), dim3(256), 0, st, det, keys2, L.m_pad, L.m_cap, counts, cap,
-                           max_nms, range, seg, 0, (float)max_wh, thr, max_det, keep, spill);
+    // score order: either the best k_target rows per image (select + sort in LDS) or all of them
+    const u64* ranked = keys;
+    int ranked_pad = L.cap_pad;
+    if (k_target > 0) {
+        ranked = (u64*)(ws + L.off_top);
+        ranked_pad = L.top_pad;
+        hipLaunchKernelGGL(k_select_sort, dim3(bs), dim3(SORT_THREADS), 0, st, keys, counts, cap, L.cap_pad, k_target, max_nms,
+                           (u64*)(ws + L.off_top), L.top_pad, m_arr, truncated);
     } else {
-        hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, bs), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, counts, cap,
-                           max_nms, range, seg, 1, (float)max_wh, thr, max_det, keep, spill);
+        hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys, counts, cap, L.cap_pad, (int2*)nullptr, 0,
+                           m_arr, max_nms);
     }
-    hipLaunchKernelGGL(k_nms_collect, dim3(bs), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, cap, max_nms,
-                       max_det, out, (long long*)nullptr, (int*)nullptr, cursor, (int2*)out_span, cand_count);
+    const int m_rows = k_target > 0 ? SORT_LDS_KEYS : L.m_cap;         // upper bound of m_arr[]
+    const dim3 ggrid((m_rows + 255) / 256, bs);
+    if (raw)
+        hipLaunchKernelGGL(k_nms_gather<true>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), ranked, ranked_pad,
+                           m_arr, det, keys2, L.m_pad, L.m_cap, range);
+    else
+        hipLaunchKernelGGL(k_nms_gather<false>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), ranked, ranked_pad,
+                           m_arr, det, keys2, L.m_pad, L.m_cap, range);
+    if (!agnostic) {
+        hipLaunchKernelGGL(k_sort_keys, dim3(bs), dim3(SORT_THREADS), 0, st, keys2, m_arr, L.m_cap, L.m_pad, seg, nc,
+                           (int*)nullptr, 0);
+        hipLaunchKernelGGL(k_nms_greedy<4>, dim3(nc, bs), dim3(256), 0, st, det, keys2, L.m_pad, L.m_cap, m_arr, range, seg, 0,
+                           (float)max_wh, thr, max_det, keep, spill);
+    } else {
+        hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, bs), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, m_arr, range, seg, 1,
+                           (float)max_wh, thr, max_det, keep, spill);
+    }
+    hipLaunchKernelGGL(k_nms_collect, dim3(bs), dim3(1024), 0, st, det, keep, ranked, ranked_pad, L.m_cap, counts, m_arr,
+                       k_target > 0 ? truncated : (const int*)nullptr, max_det, out, (long long*)nullptr, (int*)nullptr, cursor,
+                       (int2*)out_span, cand_count, needs_full);
     return dh_launch_status();
 }
 
@@ -784,8 +915,8 @@ int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A
 
 extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
                               int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
-                              int max_nms, double max_wh, int cap, float* out, int* out_span, int* cand_count,
-                              void* workspace, size_t workspace_bytes, void* stream)
+                              int max_nms, double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                              int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (bs > 0 && !pred) return DH_ERR_ARG;
     nms_source S;
@@ -793,14 +924,14 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
     S.nl = 0;
     S.no = nc + 5;
     return nms_run(S, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
-                   max_wh, cap, out, out_span, cand_count, workspace, workspace_bytes, stream);
+                   max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
 
 extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
                                   const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
                                   int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
-                                  double max_wh, int cap, float* out, int* out_span, int* cand_count, void* workspace,
-                                  size_t workspace_bytes, void* stream)
+                                  double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                  int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 6) return DH_ERR_ARG;
     if (!level_ptrs || !ny || !nx || !anchor_px || !strides) return DH_ERR_ARG;
@@ -811,13 +942,13 @@ extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny,
     uint32_t per_image = 0, rows = 0;
     if (!dh_make_levels(level_ptrs, ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image, &rows, nullptr)) return DH_ERR_ARG;
     return nms_run(S, true, nullptr, bs, (int)rows, no - 5, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det,
-                   max_nms, max_wh, cap, out, out_span, cand_count, workspace, workspace_bytes, stream);
+                   max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t dh_nms_plain_workspace(int64_t n)
 {
     if (n <= 0 || n >= (1ll << 31)) return 0;
-    return make_layout(1, (int)n, (int)n, 1).total;
+    return make_layout(1, (int)n, (int)n, 1, false).total;
 }
 
 extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
@@ -828,11 +959,12 @@ extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, 
     if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
     if (!boxes || !scores || !keep_index || !workspace) return DH_ERR_ARG;
     const int ni = (int)n;
-    const nms_layout L = make_layout(1, ni, ni, 1);
+    const nms_layout L = make_layout(1, ni, ni, 1, false);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
     int* counts = (int*)(ws + L.off_counts);
+    int* m_arr = (int*)(ws + L.off_m);
     img_range* range = (img_range*)(ws + L.off_range);
     unsigned char* keep = (unsigned char*)(ws + L.off_keep);
     u64* keys = (u64*)(ws + L.off_keys);
@@ -840,12 +972,14 @@ extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, 
     float* det = (float*)(ws + L.off_det);
     float4* spill = (float4*)(ws + L.off_spill);
     if (hipMemsetAsync(ws, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
-    hipLaunchKernelGGL(k_nms_plain_keys, dim3((ni + 255) / 256), dim3(256), 0, st, scores, ni, keys, counts);
-    hipLaunchKernelGGL(k_sort_keys, dim3(1), dim3(SORT_THREADS), 0, st, keys, counts, ni, L.cap_pad, (int2*)nullptr, 0);
+    hipLaunchKernelGGL(k_nms_plain_keys, dim3((ni + 255) / 256), dim3(256), 0, st, scores, ni, keys, counts, m_arr);
+    hipLaunchKernelGGL(k_sort_keys, dim3(1), dim3(SORT_THREADS), 0, st, keys, counts, ni, L.cap_pad, (int2*)nullptr, 0,
+                       (int*)nullptr, 0);
     hipLaunchKernelGGL(k_nms_plain_gather, dim3((ni + 255) / 256), dim3(256), 0, st, boxes, keys, ni, det);
-    hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, 1), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, counts, ni, ni, range,
+    hipLaunchKernelGGL(k_nms_greedy<16>, dim3(1, 1), dim3(1024), 0, st, det, keys2, L.m_pad, L.m_cap, m_arr, range,
                        (const int2*)nullptr, 1, 0.0f, round_down_to_float(iou_thres), ni, keep, spill);
-    hipLaunchKernelGGL(k_nms_collect, dim3(1), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, ni, ni, ni,
-                       (float*)nullptr, (long long*)keep_index, keep_count, (int*)nullptr, (int2*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(k_nms_collect, dim3(1), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, m_arr,
+                       (const int*)nullptr, ni, (float*)nullptr, (long long*)keep_index, keep_count, (int*)nullptr,
+                       (int2*)nullptr, (int*)nullptr, (int*)nullptr);
     return dh_launch_status();
 }

@@ -8,6 +8,7 @@ from .yolo import _anchor_pixels, objectness_plane
 
 MAX_WH = 7680      # general.py:663
 MAX_NMS = 30000    # general.py:664
+K_SELECT = 3840    # candidates per image that go through NMS on the first attempt (0: all); see nms_launch
 
 
 def _convert(x, mode):
@@ -97,11 +98,16 @@ def _with_apriori_labels(pred, labels, nc):
 
 
 def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-               labels=(), max_det=300, cap=None):
+               labels=(), max_det=300, cap=None, k_select=K_SELECT):
     """Enqueue the whole NMS pipeline; nothing is copied to the host (safe inside HIP graph capture).
 
     Returns (rows, meta, cap): rows (bs*max_det, 6) packed detections, meta int32 [bs x {first row, row
-    count}, bs x candidates found]; pass both to nms_finish.  (None, None, 0) when there is nothing to do.
+    count}, bs x candidates found, bs x needs-full flag]; pass both to nms_finish.  (None, None, 0) when there is
+    nothing to do.
+
+    k_select > 0: only the best-scoring k_select candidates of each image (at least 8*max_det) are sorted and go
+    through NMS, which is exact whenever they yield max_det rows (a row's fate depends only on rows ranked above
+    it); images where they do not are flagged in meta and nms_views asks for a repeat with k_select=0.
     """
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
@@ -125,14 +131,14 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     lib = L.lib()
     cap = A if cap is None else int(cap)
     rows = torch.empty((bs * max_det, 6), dtype=torch.float32, device=dev)
-    meta = torch.empty(3 * bs, dtype=torch.int32, device=dev)
+    meta = torch.empty(4 * bs, dtype=torch.int32, device=dev)
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
     with L.device_guard(dev):
         L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
-                                   int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap,
-                                   L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs), L.ptr(ws),
-                                   ws_bytes, L.stream()), "dh_nms_batched")
+                                   int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select),
+                                   L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs),
+                                   L.c_void_p(meta.data_ptr() + 12 * bs), L.ptr(ws), ws_bytes, L.stream()), "dh_nms_batched")
     return rows, meta, cap
 
 
@@ -147,7 +153,7 @@ def _class_keep(classes, nc, dev):
 
 
 def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                      multi_label=False, max_det=300, cap=None):
+                      multi_label=False, max_det=300, cap=None, k_select=K_SELECT):
     """nms_launch fed by the raw head maps: the same (rows, meta, cap) as
     nms_launch(detect_decode(levels, anchors, stride), ...), without writing or reading the decoded tensor."""
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
@@ -174,15 +180,16 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     lib = L.lib()
     cap = A if cap is None else int(cap)
     rows = torch.empty((bs * max_det, 6), dtype=torch.float32, device=dev)
-    meta = torch.empty(3 * bs, dtype=torch.int32, device=dev)
+    meta = torch.empty(4 * bs, dtype=torch.int32, device=dev)
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
     with L.device_guard(dev):
         L.check(lib.dh_yolo_decode_nms(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
                                        float(conf_thres), float(iou_thres), int(multi_label), int(bool(agnostic)),
-                                       L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, L.ptr(rows), L.ptr(meta),
-                                       L.c_void_p(meta.data_ptr() + 8 * bs), L.ptr(ws), ws_bytes, L.stream()),
+                                       L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select), L.ptr(rows),
+                                       L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs),
+                                       L.c_void_p(meta.data_ptr() + 12 * bs), L.ptr(ws), ws_bytes, L.stream()),
                 "dh_yolo_decode_nms")
     return rows, meta, cap
 
@@ -192,15 +199,19 @@ def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes
     """non_max_suppression(Detect(x)[0], ...) (val.py:194,203; detect.py:126,132) straight from the raw head maps
     `levels` (list of (bs,na,ny,nx,5+nc)); anchors / stride as Detect holds them.  Bit-identical to the two-call
     sequence, at about half its HBM traffic: the decoded (bs, A, 5+nc) tensor is neither written nor read."""
-    cap = None
+    cap, k_select = None, K_SELECT
     while True:
         rows, meta, cap = detect_nms_launch(levels, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
-                                            max_det, cap)
+                                            max_det, cap, k_select)
         if rows is None:
             return [torch.zeros((0, 6), device=levels[0].device)] * levels[0].shape[0]
-        result, cap = nms_finish(rows, meta, cap)
+        result, need = nms_finish(rows, meta, cap)
         if result is not None:
             return result
+        if need < 0:
+            k_select = 0
+        else:
+            cap = need
 
 
 def nms_meta_to_host(meta, pinned=None):
@@ -218,10 +229,15 @@ def nms_meta_to_host(meta, pinned=None):
 
 
 def nms_views(rows, host, cap):
-    """Per-image (k,6) views of the packed rows from the host copy of meta; (None, needed_cap) on overflow."""
-    bs = len(host) // 3
-    if max(host[2 * bs:]) > cap:
-        return None, max(host[2 * bs:])
+    """Per-image (k,6) views of the packed rows from the host copy of meta.
+
+    (None, needed_cap) when the candidate capacity overflowed, (None, -1) when some image needs the full sort
+    (see nms_launch): the caller repeats the launch with that cap, or with k_select=0."""
+    bs = len(host) // 4
+    if max(host[2 * bs:3 * bs]) > cap:
+        return None, max(host[2 * bs:3 * bs])
+    if any(host[3 * bs:]):
+        return None, -1
     # images are packed in completion order: one split() call makes every per-image view
     first, count = host[0:2 * bs:2], host[1:2 * bs:2]
     order = [i for i in sorted(range(bs), key=first.__getitem__) if count[i]]
@@ -245,12 +261,16 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     of the per-image counts; the returned tensors are views of one packed buffer.
     The reference's 10 s wall-clock bail-out (general.py:734-736) is not reproduced.
     """
-    cap = None
+    cap, k_select = None, K_SELECT
     while True:
-        rows, meta, cap = nms_launch(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det, cap)
+        rows, meta, cap = nms_launch(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det, cap,
+                                     k_select)
         if rows is None:
             return [torch.zeros((0, 6), device=prediction.device)] * prediction.shape[0]
-        result, cap = nms_finish(rows, meta, cap)
+        result, need = nms_finish(rows, meta, cap)
         if result is not None:
             return result
-        # multi-label produced more candidates than rows: rerun with room for all of them
+        if need < 0:
+            k_select = 0      # the best-scoring prefix did not yield max_det rows somewhere: sort everything
+        else:
+            cap = need        # multi-label produced more candidates than rows: rerun with room for all of them

@@ -216,3 +216,34 @@ def test_fused_decode_nms_equals_two_calls_and_oracle(kw):
     same_lists(fused, two)
     same_lists(fused, onms.non_max_suppression(z.cpu().clone(), **kw))
     assert sum(t.shape[0] for t in two) > 20
+
+
+def test_nms_prefix_selection_and_its_fallback():
+    """Only the best-scoring few thousand candidates go through NMS on the first attempt.  (a) plenty of distinct
+    objects: the prefix yields max_det rows and is final; (b) one tight cluster: it does not, the launch says so, and
+    the wrapper repeats with the full sort.  Both must equal the oracle."""
+    from object_detection_amd.general import nms_finish, nms_launch, non_max_suppression
+    rs = np.random.RandomState(5)
+    bs, A, nc = 3, 9000, 3
+    pred = np.zeros((bs, A, 5 + nc), dtype=np.float32)
+    pred[..., 0:2] = rs.uniform(0, 640, (bs, A, 2))
+    pred[..., 2:4] = rs.uniform(4, 12, (bs, A, 2))                     # small boxes: most survive
+    pred[..., 4] = rs.uniform(0.5, 1, (bs, A))
+    pred[..., 5:] = rs.uniform(0.5, 1, (bs, A, nc))
+    pred[1, :, 0:2] = 320 + rs.uniform(-2, 2, (A, 2))                  # image 1: one cluster, a handful survive
+    pred[1, :, 2:4] = 100
+    kw = dict(conf_thres=0.25, iou_thres=0.45, max_det=300)
+    want = onms.non_max_suppression(T(pred).clone(), **kw)
+    assert want[0].shape[0] == 300 and want[1].shape[0] < 50
+    dev = T(pred).cuda()
+    rows, meta, cap = nms_launch(dev, **kw)
+    flags = meta.cpu().numpy()[3 * bs:]
+    np.testing.assert_array_equal(flags, [0, 1, 0])
+    assert nms_finish(rows, meta, cap) == (None, -1)
+    rows, meta, cap = nms_launch(dev, k_select=0, **kw)
+    assert not meta.cpu().numpy()[3 * bs:].any()
+    same_lists(nms_finish(rows, meta, cap)[0], want)
+    same_lists(non_max_suppression(dev, **kw), want)
+    # multi-label: 3 candidates per row, 27000 per image
+    kw = dict(conf_thres=0.25, iou_thres=0.45, max_det=300, multi_label=True)
+    same_lists(non_max_suppression(dev, **kw), onms.non_max_suppression(T(pred).clone(), **kw))
