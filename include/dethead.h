@@ -178,6 +178,18 @@ int dh_centernet_decode(const float* heat, const float* size, const float* offse
                         double confidence, float* det, int* counts, void* workspace, size_t workspace_bytes,
                         void* stream);
 
+/* CenterNet postprocess, device part (object_detection/detectors/centernet/dataset.py:246-270): the detections of each
+ * image regrouped by ascending class; with need_nms every class goes through torchvision nms(boxes, scores, nms_thres)
+ * and keeps the survivors in score order (equal scores: input order), without it a class keeps its input order.
+ * rows (*, 6) [x1,y1,x2,y2,conf,cls]: image b owns count[b] rows starting at row first[b] (so both a concatenation
+ * and the padded (B, W*H, 6) buffer of dh_centernet_decode fit); max_rows >= every count, nc > every class id.
+ * out: image b's result starts at row out_first[b] and has out_count[b] <= count[b] rows.  first, count, out_first,
+ * out_count are device arrays of n_img ints.  One sequence of launches for the whole batch; nothing returns to the host. */
+size_t dh_group_nms_workspace(int n_img, int max_rows, int nc);
+int dh_group_nms(const float* rows, const int* first, const int* count, const int* out_first, int n_img, int max_rows, int nc,
+                 int need_nms, double nms_thres, float* out, int* out_count, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
 /* Target maps of CenternetDataset.__getitem__ (dataset.py:103-150) for a batch: labels (B,Lmax,5)
  * [x1,y1,x2,y2,cls] in input pixels with nlabels (B) valid rows each; outputs t_cls (B,C,W,H),
  * t_size / t_offset (B,2,W,H), t_mask (B,W,H); owner_ws is B*W*H ints of scratch.  All device memory. */

@@ -9,7 +9,6 @@ import torch
 
 from . import _lib as L
 from .loss import IoULossWithMask, masked_ciou_loss
-from .ops import nms
 
 
 def pool_nms(heat, kernel=3):
@@ -22,6 +21,15 @@ def pool_nms(heat, kernel=3):
         L.check(L.lib().dh_centernet_pool_nms(L.ptr(h), L.ptr(out), h.shape[0] * h.shape[1], h.shape[2], h.shape[3],
                                               int(kernel), L.stream()), "dh_centernet_pool_nms")
     return out
+
+
+class _Decoded(list):
+    """decode_bbox's per-image list, which also remembers the padded device buffer the entries are views of, so that
+    postprocess can hand the whole batch to one kernel sequence without concatenating them again."""
+    buffer = None        # (B, W*H, 6)
+    counts = None        # device int32 (B,)
+    num_classes = 0
+    version = -1         # autograd version counter of the buffer when it was written
 
 
 def decode_bbox(pred_cls, pred_size, pred_offset, confidence, device=None):
@@ -44,7 +52,9 @@ def decode_bbox(pred_cls, pred_size, pred_offset, confidence, device=None):
     with L.device_guard(heat.device):
         L.check(lib.dh_centernet_decode(L.ptr(heat), L.ptr(size), L.ptr(off), B, C, W, H, float(confidence), L.ptr(det),
                                         L.ptr(counts), L.ptr(ws), ws_bytes, L.stream()), "dh_centernet_decode")
-    return [det[i, :k] if k else [] for i, k in enumerate(counts.tolist())]
+    out = _Decoded(det[i, :k] if k else [] for i, k in enumerate(counts.tolist()))
+    out.buffer, out.counts, out.num_classes, out.version = det, counts, int(C), det._version
+    return out
 
 
 def centernet_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image):
@@ -64,23 +74,60 @@ def centernet_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_
     return boxes
 
 
+def _group_by_class(prediction, need_nms, nms_thres):
+    """Device part of postprocess for the whole batch: rows of every image regrouped by ascending class, each class
+    through NMS when asked.  Returns (rows on the host (n,6) float32, [first row, row count] per image)."""
+    sizes = [len(d) for d in prediction]
+    B = len(sizes)
+    out_first = [0] * B
+    for i in range(1, B):
+        out_first[i] = out_first[i - 1] + sizes[i - 1]
+    total = out_first[-1] + sizes[-1]
+    if isinstance(prediction, _Decoded) and prediction.buffer is not None and all(
+            len(d) == 0 or (d.data_ptr() == prediction.buffer[i].data_ptr() and d._version == prediction.version)
+            for i, d in enumerate(prediction)):      # still the untouched views decode_bbox made
+        rows = prediction.buffer.view(-1, 6)
+        stride = prediction.buffer.shape[1]
+        first = [i * stride for i in range(B)]
+        nc = prediction.num_classes
+    else:
+        rows = torch.cat([L.dev_f32(d, f"prediction[{i}]").reshape(-1, 6) for i, d in enumerate(prediction) if len(d)])
+        first = out_first
+        nc = int(rows[:, 5].max()) + 1          # the only place that has to look at the data before launching
+        if nc < 1 or int(rows[:, 5].min()) < 0:
+            raise RuntimeError("postprocess: class ids must be non-negative")
+    dev = rows.device
+    index = torch.tensor([first, sizes, out_first], dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+    out = torch.empty((total, 6), dtype=torch.float32, device=dev)
+    out_count = torch.empty(B, dtype=torch.int32, device=dev)
+    lib = L.lib()
+    ws_bytes = lib.dh_group_nms_workspace(B, max(sizes), nc)
+    ws = L.workspace(ws_bytes, dev)
+    with L.device_guard(dev):
+        L.check(lib.dh_group_nms(L.ptr(rows), L.ptr(index[0]), L.ptr(index[1]), L.ptr(index[2]), B, max(sizes), nc,
+                                 int(bool(need_nms)), float(nms_thres), L.ptr(out), L.ptr(out_count), L.ptr(ws), ws_bytes,
+                                 L.stream()), "dh_group_nms")
+    return out.cpu().numpy(), list(zip(out_first, out_count.tolist()))
+
+
 def postprocess(prediction, need_nms, image_shape, input_shape, letterbox_image, nms_thres=0.4):
     """dataset.py:246-284 -> list of numpy (k,6) arrays or None; rows grouped by ascending class,
-    inside a class in score order when need_nms else in input order."""
+    inside a class in score order when need_nms else in input order.
+
+    The class grouping and the per-class NMS of every image run as one sequence of launches (the reference loops
+    over images and classes with a host round trip each); the box rescaling stays the reference's numpy arithmetic on
+    the host, where the result has to end up anyway."""
     output = [None for _ in range(len(prediction))]
-    for i, det in enumerate(prediction):
-        if len(det) == 0:
+    if not any(len(d) for d in prediction):
+        return output
+    rows, spans = _group_by_class(prediction, need_nms, nms_thres)
+    for i, (start, k) in enumerate(spans):
+        if len(prediction[i]) == 0:
             continue
-        for c in det[:, -1].unique():
-            same = det[det[:, -1] == c]
-            if need_nms:
-                same = same[nms(same[:, :4], same[:, 4], nms_thres)]
-            output[i] = same if output[i] is None else torch.cat((output[i], same))
-        if output[i] is not None:
-            arr = output[i].cpu().detach().numpy()
-            box_xy, box_wh = (arr[:, 0:2] + arr[:, 2:4]) / 2, arr[:, 2:4] - arr[:, 0:2]
-            arr[:, :4] = centernet_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image)
-            output[i] = arr
+        arr = rows[start:start + k].copy()
+        box_xy, box_wh = (arr[:, 0:2] + arr[:, 2:4]) / 2, arr[:, 2:4] - arr[:, 0:2]
+        arr[:, :4] = centernet_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image)
+        output[i] = arr
     return output
 
 

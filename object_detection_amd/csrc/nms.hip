@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
     const int m = m_arr[b];
     if (m == 0) return;
     bool whole = agnostic != 0;
-    if (!whole) {
+    if (!whole && max_wh >= 0.0f) {      // max_wh < 0: every class is its own unshifted problem (plain per-class nms)
         const img_range rg = range[b];
         const float lo = ukey_float(~rg.lo_inv), hi = ukey_float(rg.hi_key);
         whole = rg.bad != 0 || !(hi - lo < max_wh - 1.0f);
@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
     __shared__ u64 cmask[64];
     __shared__ int s_kept;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const float off_scale = agnostic ? 0.0f : max_wh;
+    const float off_scale = (agnostic || max_wh < 0.0f) ? 0.0f : max_wh;
     int kept = 0;
 
     for (int base = s; base < e && kept < max_det; base += 64) {
@@ -743,6 +743,78 @@ __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ 
         done += all;
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------ grouped rows (CenterNet)
+// Ready-made detection rows [x1,y1,x2,y2,conf,cls] of several images (image b = count[b] rows from row first[b])
+// instead of a prediction tensor: keys from the row's own score (or none: input order), gather by row index, and a collect
+// that walks the (class, rank) order so the output is grouped by ascending class.
+__global__ void __launch_bounds__(256) k_rows_keys(const float* __restrict__ rows, const int* __restrict__ first,
+                                                   const int* __restrict__ count, int max_rows, int use_score,
+                                                   u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
+{
+    const int b = blockIdx.y;
+    const int f = first[b];
+    int n = count[b];
+    n = n < 0 ? 0 : (n > max_rows ? max_rows : n);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) counts[b] = n;
+    if (j < n) keys[(size_t)b * cap_pad + j] = ((u64)(use_score ? score_key(rows[(size_t)(f + j) * 6 + 4]) : 0u) << 32) | (uint32_t)j;
+}
+
+__global__ void __launch_bounds__(256) k_rows_gather(const float* __restrict__ rows, const int* __restrict__ first,
+                                                     const u64* __restrict__ keys, int cap_pad, const int* __restrict__ m_arr,
+                                                     float* __restrict__ det, u64* __restrict__ keys2, int m_pad, int m_cap,
+                                                     int nc)
+{
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m_arr[b]) return;
+    const uint32_t j = (uint32_t)keys[(size_t)b * cap_pad + r];
+    const float* __restrict__ p = rows + (size_t)(first[b] + j) * 6;
+    float* __restrict__ d = det + ((size_t)b * m_cap + r) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) d[q] = p[q];
+    int cls = (int)p[5];
+    cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);      // the caller guarantees 0 <= class < nc; never index outside the table
+    keys2[(size_t)b * m_pad + r] = ((u64)(uint32_t)cls << 32) | (uint32_t)r;
+}
+
+__global__ void __launch_bounds__(1024) k_rows_collect(const float* __restrict__ det, const unsigned char* __restrict__ keep,
+                                                       const u64* __restrict__ keys2, int m_pad, int m_cap,
+                                                       const int* __restrict__ m_arr, const int* __restrict__ out_first, int use_keep,
+                                                       float* __restrict__ out, int* __restrict__ out_count)
+{
+    const int b = blockIdx.x;
+    const int m = m_arr[b];
+    __shared__ int wcount[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* __restrict__ o_img = out + (size_t)out_first[b] * 6;
+    int done = 0;
+    for (int base = 0; base < m; base += 1024) {
+        const int p = base + threadIdx.x;
+        int rank = 0;
+        bool k = false;
+        if (p < m) {
+            rank = (int)(uint32_t)keys2[(size_t)b * m_pad + p];
+            k = !use_keep || keep[(size_t)b * m_cap + rank] != 0;
+        }
+        const u64 bm = __ballot(k);
+        if (lane == 0) wcount[wave] = __popcll(bm);
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = wcount[w]; if (w < wave) before += c; all += c; }
+        if (k) {
+            const float* __restrict__ d = det + ((size_t)b * m_cap + rank) * 6;
+            float* __restrict__ o = o_img + (size_t)(done + before + __popcll(bm & lanemask_lt())) * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) o[q] = d[q];
+        }
+        done += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_count[b] = done;
 }
 
 // plain nms(): keys from scores, det rows from boxes
@@ -943,6 +1015,50 @@ extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny,
     if (!dh_make_levels(level_ptrs, ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image, &rows, nullptr)) return DH_ERR_ARG;
     return nms_run(S, true, nullptr, bs, (int)rows, no - 5, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det,
                    max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t dh_group_nms_workspace(int n_img, int max_rows, int nc)
+{
+    if (n_img <= 0 || max_rows <= 0 || nc <= 0) return 0;
+    return make_layout(n_img, max_rows, max_rows, nc, false).total;
+}
+
+extern "C" int dh_group_nms(const float* rows, const int* first, const int* count, const int* out_first, int n_img, int max_rows,
+                            int nc, int need_nms, double nms_thres, float* out, int* out_count, void* workspace,
+                            size_t workspace_bytes, void* stream)
+{
+    if (n_img < 0 || n_img > 65535 || max_rows < 0 || nc < 1) return DH_ERR_ARG;
+    if (n_img == 0) return DH_OK;
+    if (!first || !count || !out_first || !out_count || !workspace) return DH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (max_rows == 0) return hipMemsetAsync(out_count, 0, sizeof(int) * n_img, st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (!rows || !out) return DH_ERR_ARG;
+    const nms_layout L = make_layout(n_img, max_rows, max_rows, nc, false);
+    if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    int* counts = (int*)(ws + L.off_counts);
+    int* m_arr = (int*)(ws + L.off_m);
+    img_range* range = (img_range*)(ws + L.off_range);
+    int2* seg = (int2*)(ws + L.off_seg);
+    unsigned char* keep = (unsigned char*)(ws + L.off_keep);
+    u64* keys = (u64*)(ws + L.off_keys);
+    u64* keys2 = (u64*)(ws + L.off_keys2);
+    float* det = (float*)(ws + L.off_det);
+    float4* spill = (float4*)(ws + L.off_spill);
+    if (hipMemsetAsync(ws, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
+    const dim3 grid((max_rows + 255) / 256, n_img);
+    hipLaunchKernelGGL(k_rows_keys, grid, dim3(256), 0, st, rows, first, count, max_rows, need_nms ? 1 : 0, keys, L.cap_pad, counts);
+    hipLaunchKernelGGL(k_sort_keys, dim3(n_img), dim3(SORT_THREADS), 0, st, keys, counts, max_rows, L.cap_pad, (int2*)nullptr, 0,
+                       m_arr, max_rows);
+    hipLaunchKernelGGL(k_rows_gather, grid, dim3(256), 0, st, rows, first, keys, L.cap_pad, m_arr, det, keys2, L.m_pad, L.m_cap, nc);
+    hipLaunchKernelGGL(k_sort_keys, dim3(n_img), dim3(SORT_THREADS), 0, st, keys2, m_arr, L.m_cap, L.m_pad, seg, nc, (int*)nullptr, 0);
+    if (need_nms)
+        hipLaunchKernelGGL(k_nms_greedy<4>, dim3(nc, n_img), dim3(256), 0, st, det, keys2, L.m_pad, L.m_cap, m_arr, range, seg, 0,
+                           -1.0f, round_down_to_float(nms_thres), max_rows, keep, spill);
+    hipLaunchKernelGGL(k_rows_collect, dim3(n_img), dim3(1024), 0, st, det, keep, keys2, L.m_pad, L.m_cap, m_arr, out_first,
+                       need_nms ? 1 : 0, out, out_count);
+    return dh_launch_status();
 }
 
 extern "C" size_t dh_nms_plain_workspace(int64_t n)

@@ -120,3 +120,36 @@ def test_centernet_targets(golden):
         want = oc.draw_targets(l, 80, (640, 640), (160, 160))
         for nm, arr, w in zip(("cls", "size", "offset", "mask"), got, want):
             np.testing.assert_array_equal(arr[k].cpu().numpy(), w, err_msg=f"{nm} img{k}")
+
+
+def test_centernet_postprocess_batch_vs_oracle():
+    """Whole-batch class grouping + per-class NMS: many classes, clusters that NMS has to thin out, equal scores,
+    an empty image; both the list straight from decode_bbox and a list of unrelated tensors."""
+    from object_detection_amd import centernet as C
+    from oracle import centernet as oc
+    rs = np.random.RandomState(77)
+    B, nc, W, H = 5, 20, 64, 48
+    heat = rs.uniform(-3, 0.2, (B, nc, W, H)).astype(np.float32)
+    size = rs.uniform(2, 12, (B, 2, W, H)).astype(np.float32)
+    off = rs.uniform(0, 1, (B, 2, W, H)).astype(np.float32)
+    heat[2] = -5.0                                            # image 2: nothing above the threshold
+    for b in (0, 1, 3, 4):                                    # isolated peaks so that pool_nms keeps them
+        for _ in range(150):
+            c, x, y = rs.randint(nc), rs.randint(1, W - 1), rs.randint(1, H - 1)
+            heat[b, c, x, y] = rs.uniform(1.0, 3.0)
+    heat[4, 3, 10, 10] = heat[4, 3, 30, 30] = 2.5             # equal scores in one class
+    th, ts, to = T(heat).cuda(), T(size).cuda(), T(off).cuda()
+    dets = C.decode_bbox(th, ts, to, 0.5, "cuda")
+    assert isinstance(dets, list) and len(dets[2]) == 0 and min(len(dets[b]) for b in (0, 1, 3, 4)) > 50
+    cpu = [d.cpu() if len(d) else [] for d in dets]
+    for need, thres in ((True, 0.05), (True, 0.4), (False, 0.4)):
+        want = oc.postprocess([d.clone() if len(d) else d for d in cpu], need, 640, 160.0, False, thres)
+        for got in (C.postprocess(dets, need, 640, 160.0, False, thres),
+                    C.postprocess([d.clone() if len(d) else d for d in dets], need, 640, 160.0, False, thres)):
+            for g, w in zip(got, want):
+                assert (g is None) == (w is None)
+                if g is not None:
+                    assert g.dtype == np.float32
+                    np.testing.assert_array_equal(g, w)
+    thin = oc.postprocess([d.clone() if len(d) else d for d in cpu], True, 640, 160.0, False, 0.05)
+    assert sum(len(t) for t in thin if t is not None) < sum(len(d) for d in cpu)
