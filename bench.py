@@ -138,8 +138,6 @@ def main():
     ap.add_argument("--autograd", action="store_true",
                     help="call loss = crit(p, t); autograd.grad(loss, p) instead of crit.forward_backward(p, t): same kernels, "
                          "plus the autograd engine's hop to its device thread and back (two thread wake-ups per step)")
-    ap.add_argument("--graph", action="store_true",
-                    help="EXPERIMENTAL: replay one captured HIP graph per stage instead of launching from Python")
     args = ap.parse_args()
 
     if os.environ.get("DH_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack if the run stalls
@@ -178,9 +176,6 @@ def main():
     level_shapes = [(int(x.shape[2]), int(x.shape[3])) for x in levels]
 
     from object_detection_amd.general import nms_launch, nms_meta_to_host, nms_views, non_max_suppression
-    from object_detection_amd.graphs import GraphedStage
-
-    use_graph = args.graph
     stages = ("decode", "assign+loss_fwd+bwd", "nms", "d2h")
     ev = {s: [] for s in stages}
     cap = A
@@ -197,18 +192,11 @@ def main():
             grads = torch.autograd.grad(loss, p)
         return loss, items, grads, crit.last_stats       # [lbox, lobj, lcls, n_pos], written by the loss kernel
 
-    if use_graph:   # one HIP graph per stage so that events between replays still bracket each stage
-        g_decode = GraphedStage(f_decode)
-        z_static = g_decode.outputs
-        g_loss = GraphedStage(f_loss)
-        g_decode.replay()      # give the NMS warm-up real predictions to work on
-        g_nms = GraphedStage(lambda: nms_launch(z_static, 0.25, 0.45, max_det=300, cap=cap))
-
     host_s = {s: 0.0 for s in stages + ("finish",)}
     # Three HIP streams: decode on the main stream; the NMS chain (short, latency-bound kernels that read the decoded
     # tensor) on a second; assignment + loss forward/backward (bandwidth-bound, reads the raw maps and the logit plane
     # the decode left behind) on a third.  Both wait for the step's decode; the next step's decode does not wait for them.
-    n_streams = 1 if use_graph else args.streams
+    n_streams = args.streams
     overlap = n_streams > 1
     torch.cuda.synchronize()
     if overlap:      # keep the legacy null stream (which the runtime orders against every other stream) out of the loop
@@ -231,7 +219,7 @@ def main():
             assigned.record()
             set_stream(main_stream)
         if record: marks[0].record()
-        z = g_decode.replay() if use_graph else f_decode()
+        z = f_decode()
         if record: marks[1].record()
         h1 = time.perf_counter()
         if overlap:
@@ -242,7 +230,7 @@ def main():
                 loss_stream.wait_event(decoded)
             set_stream(nms_stream)
         if record: marks[3].record()
-        rows, meta, _ = g_nms.replay() if use_graph else nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
+        rows, meta, _ = nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
         if record: marks[4].record()
         host_meta, copied = nms_meta_to_host(meta)           # the step's only device-to-host copy (4*bs ints)
         if record: marks[5].record()
@@ -252,7 +240,7 @@ def main():
             if assign_early:
                 loss_stream.wait_event(assigned)
         if record: marks[6].record()
-        loss, items, grads, stats = g_loss.replay() if use_graph else f_loss(assignment)
+        loss, items, grads, stats = f_loss(assignment)
         h3 = time.perf_counter()
         if record: marks[2].record()
         if world > 1:
@@ -357,7 +345,6 @@ def main():
                 ("p10", "p50", "p90", "max", "argmax"), list(np.percentile(np.diff(step_wall), (10, 50, 90, 100))) +
                 [int(np.argmax(np.diff(step_wall))) * 1e-3])} if len(step_wall) > 2 else None,
             "collective": "one all_reduce(SUM) of [lbox, lobj, lcls, n_pos] per step over RCCL, on the side stream" if world > 1 else None,
-            "launch_mode": "hip-graph per stage" if use_graph else "eager",
             "loss_call": "crit(p,t) + torch.autograd.grad" if args.autograd else "crit.forward_backward(p,t)",
             "streams": {1: "one stream", 2: "decode, assign+loss | nms chain on two streams (stage_ms overlap)",
                         3: "decode | nms chain | assign+loss on three streams (stage_ms overlap)"}[n_streams],
