@@ -40,3 +40,11 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("oracle/", ""), f"{f} mentions the oracle"
+
+
+def test_bench_cpu_baseline_leg_runs_on_the_oracle():
+    """bench.py's cpu_baseline leg is the oracle on a bounded sample; it must work without a GPU."""
+    import bench
+    out = bench.cpu_baseline(seconds_budget=0.2)
+    assert out["kind"] == "port" and out["unit"] == "images/s" and out["value"] > 0 and out["cores"] >= 1
+    assert "bs 8" in out["sample"]
