@@ -207,9 +207,12 @@ def main():
     set_stream = torch.cuda.set_stream
     assign_early = overlap and os.environ.get("DH_BENCH_ASSIGN_EARLY", "0") == "1"
 
-    def launch(record):
-        """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation."""
+    def launch(record, detail=False):
+        """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation.
+        record: bracket the decode launch with timing events (every timed step); detail: also the other stages
+        (every 4th timed step: each event is a marker packet in the queue and costs host time, too)."""
         marks = mark_pool.pop() if record else None
+        detail = detail and record
         h0 = time.perf_counter()
         assignment = None
         if assign_early:      # target assignment needs only the targets: enqueue it beside the decode
@@ -229,20 +232,20 @@ def main():
             if n_streams == 3:
                 loss_stream.wait_event(decoded)
             set_stream(nms_stream)
-        if record: marks[3].record()
+        if detail: marks[3].record()
         rows, meta, _ = nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
-        if record: marks[4].record()
+        if detail: marks[4].record()
         host_meta, copied = nms_meta_to_host(meta)           # the step's only device-to-host copy (4*bs ints)
-        if record: marks[5].record()
+        if detail: marks[5].record()
         h2 = time.perf_counter()
         if overlap:
             set_stream(loss_stream)
             if assign_early:
                 loss_stream.wait_event(assigned)
-        if record: marks[6].record()
+        if detail: marks[6].record()
         loss, items, grads, stats = f_loss(assignment)
         h3 = time.perf_counter()
-        if record: marks[2].record()
+        if detail: marks[2].record()
         if world > 1:
             stats = stats.clone() if backend == "nccl" else stats.cpu()   # (host tensor only in the gloo rehearsal)
             if overlap:      # the collective waits for the loss on the side stream: the next decode does not wait for the other ranks
@@ -274,14 +277,14 @@ def main():
     def run(n, record):
         """n steps, software-pipelined: the host half of step i runs while the GPU works on step i+1."""
         all_marks, prev, dets = [], None, None
-        for _ in range(n):
+        for i in range(n):
             if record:
                 step_wall.append(time.perf_counter())
-            job = launch(record)
+            job = launch(record, i % 4 == 0)
             if prev is not None:
                 dets = finish(prev)      # prev's tensors are released here, so the allocator reuses its blocks
             prev = job
-            all_marks.append(job["marks"])
+            all_marks.append((job["marks"], i % 4 == 0))
         if prev is not None:
             dets = finish(prev)
         return all_marks, dets
@@ -307,9 +310,10 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    for marks in all_marks:     # decode and loss are bracketed on the main stream, nms and the copy on the stream they ran on
+    for marks, detail in all_marks:     # decode and loss are bracketed on the main stream, nms and the copy on the stream they ran on
         for s, (a, b) in zip(stages, ((0, 1), (6, 2), (3, 4), (4, 5))):
-            ev[s].append(marks[a].elapsed_time(marks[b]))
+            if detail or s == "decode":
+                ev[s].append(marks[a].elapsed_time(marks[b]))
     if world > 1:
         tmax = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
