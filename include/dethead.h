@@ -123,6 +123,12 @@ int dh_box_convert(const float* in, int64_t in_row_stride, float* out, int64_t o
 int dh_scale_clip_coords(float* boxes, int64_t row_stride, int64_t n, int do_scale, double pad_x, double pad_y,
                          double gain, double max_x, double max_y, void* stream);
 
+/* In-place de-scaling of augmented-inference predictions (object_detection/yolov5/models/yolo.py:155-163, the
+ * in-place branch): columns 0..3 of n rows are divided by scale, then flips == 2 sets y = img_h - y and flips == 3
+ * x = img_w - x.  row_stride in floats (>= 4). */
+int dh_descale_pred(float* rows, int64_t row_stride, int64_t n, double scale, int flips, double img_h, double img_w,
+                    void* stream);
+
 /* ComputeLoss.build_targets (object_detection/yolov5/utils/loss.py:169-222) for all nl levels.
  * targets (nt,6) [image,class,x,y,w,h] and anchors (nl,na,2, grid units) on the device; ny/nx host
  * arrays.  Per level l, rows [0,counts[l]) of:  idx[l][0..3][cap] = image, anchor, gj, gi planes

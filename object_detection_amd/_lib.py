@@ -43,6 +43,7 @@ SIGNATURES = {
     "dh_box_convert": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "dh_scale_clip_coords": (c_int, [c_void_p, c_i64, c_i64, c_int, c_double, c_double, c_double, c_double, c_double,
                                      c_void_p]),
+    "dh_descale_pred": (c_int, [c_void_p, c_i64, c_i64, c_double, c_int, c_double, c_double, c_void_p]),
     "dh_build_targets_workspace": (c_size_t, [c_int, c_int, c_i64]),
     "dh_build_targets": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_double, c_i64, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -1,7 +1,8 @@
 // Box-format helpers on (n, >=4) row-major tensors.
 //
 // Reference: object_detection/yolov5/utils/general.py:543-560 (xyxy2xywh, xywh2xyxy),
-//            :619-644 (scale_coords, clip_coords; both modify the caller's tensor in place).
+//            :619-644 (scale_coords, clip_coords; both modify the caller's tensor in place),
+//            object_detection/yolov5/models/yolo.py:155-163 (_descale_pred, in-place branch).
 #include "dh_common.h"
 #include "../../include/dethead.h"
 
@@ -40,7 +41,30 @@ __global__ void __launch_bounds__(256) k_scale_clip(float* __restrict__ boxes, l
     p[3] = fminf(fmaxf(y2, 0.0f), max_y);
 }
 
+__global__ void __launch_bounds__(256) k_descale(float* __restrict__ rows, long stride, long n, float scale, int flips,
+                                                 float img_h, float img_w)
+{
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* p = rows + i * stride;
+    float x = __fdiv_rn(p[0], scale), y = __fdiv_rn(p[1], scale);                 // yolo.py:158
+    const float w = __fdiv_rn(p[2], scale), h = __fdiv_rn(p[3], scale);
+    if (flips == 2) y = img_h - y;                                               // yolo.py:160
+    else if (flips == 3) x = img_w - x;                                          // yolo.py:162
+    p[0] = x; p[1] = y; p[2] = w; p[3] = h;
+}
+
 }  // namespace
+
+extern "C" int dh_descale_pred(float* rows, int64_t row_stride, int64_t n, double scale, int flips, double img_h, double img_w,
+                               void* stream)
+{
+    if (n < 0 || (n > 0 && !rows) || row_stride < 4) return DH_ERR_ARG;
+    if (n == 0) return DH_OK;
+    hipLaunchKernelGGL(k_descale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, (long)row_stride,
+                       (long)n, (float)scale, flips, (float)img_h, (float)img_w);
+    return dh_launch_status();
+}
 
 extern "C" int dh_box_convert(const float* in, int64_t in_row_stride, float* out, int64_t out_row_stride, int64_t n,
                               int mode, void* stream)

@@ -54,6 +54,7 @@ def _scale_clip(boxes, do_scale, pad, gain, shape):
         L.check(L.lib().dh_scale_clip_coords(L.ptr(boxes), boxes.stride(0), boxes.shape[0], int(do_scale), float(pad[0]),
                                              float(pad[1]), float(gain), float(shape[1]), float(shape[0]), L.stream()),
                 "dh_scale_clip_coords")
+    torch.autograd.graph.increment_version(boxes)      # written through the raw pointer: keep the version counter honest
 
 
 def clip_coords(boxes, shape):

@@ -109,6 +109,31 @@ def detect_decode(levels, anchors, stride):
     return out
 
 
+def descale_pred(p, flips, scale, img_size):
+    """Model._descale_pred, in-place branch (yolo.py:155-163): p (..., no) decoded predictions of one augmented pass;
+    boxes /= scale, flips 2 / 3 mirror y / x back inside img_size = (height, width).  Modifies and returns p."""
+    if p.dtype != torch.float32 or not p.is_cuda or p.dim() < 2 or p.shape[-1] < 4 or not p.is_contiguous():
+        raise RuntimeError(f"descale_pred modifies contiguous fp32 ROCm tensors (..., >=4) in place; got {p.dtype} "
+                           f"{tuple(p.shape)} on {p.device}")
+    rows = p.numel() // p.shape[-1]
+    with L.device_guard(p.device):
+        L.check(L.lib().dh_descale_pred(L.ptr(p), int(p.shape[-1]), rows, float(scale), int(flips) if flips else 0,
+                                        float(img_size[0]), float(img_size[1]), L.stream()), "dh_descale_pred")
+    torch.autograd.graph.increment_version(p)      # the kernel wrote through the raw pointer: keep the version counter honest
+    return p
+
+
+def clip_augmented(y, nl):
+    """Model._clip_augmented (yolo.py:174-183): drop the tails of the first and last augmented outputs (views only)."""
+    g = sum(4 ** x for x in range(nl))
+    e = 1
+    i = (y[0].shape[1] // g) * sum(4 ** x for x in range(e))
+    y[0] = y[0][:, :-i]
+    i = (y[-1].shape[1] // g) * sum(4 ** (nl - 1 - x) for x in range(e))
+    y[-1] = y[-1][:, i:]
+    return y
+
+
 class Detect(nn.Module):
     """Same constructor, buffers and forward contract as yolo.py:33-70.
 

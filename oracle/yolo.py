@@ -166,3 +166,24 @@ class YoloLossOracle:
         lcls = lcls * self.hyp["cls"]
         bs = p[0].shape[0]
         return (lbox + lobj + lcls) * bs, torch.cat((lbox, lobj, lcls)).detach()
+
+
+def descale_pred(p, flips, scale, img_size):
+    """Model._descale_pred, in-place branch (object_detection/yolov5/models/yolo.py:155-163)."""
+    p[..., :4] /= scale
+    if flips == 2:
+        p[..., 1] = img_size[0] - p[..., 1]
+    elif flips == 3:
+        p[..., 0] = img_size[1] - p[..., 0]
+    return p
+
+
+def clip_augmented(y, nl):
+    """Model._clip_augmented (object_detection/yolov5/models/yolo.py:174-183)."""
+    g = sum(4 ** x for x in range(nl))
+    e = 1
+    i = (y[0].shape[1] // g) * sum(4 ** x for x in range(e))
+    y[0] = y[0][:, :-i]
+    i = (y[-1].shape[1] // g) * sum(4 ** (nl - 1 - x) for x in range(e))
+    y[-1] = y[-1][:, i:]
+    return y

@@ -160,3 +160,27 @@ def test_1280px_head_decode_nms_vs_oracle():
     same_lists(non_max_suppression(z, **kw), ref)
     same_lists(detect_nms(dev, anchors.cuda(), strides, **kw), ref)
     assert ref[0].shape[0] == 300
+
+
+def test_tta_descale_and_clip_vs_oracle():
+    """Augmented inference: de-scale / de-flip in place (bit-exact: IEEE division and subtraction), tail clipping."""
+    from object_detection_amd.general import clip_coords
+    from object_detection_amd.yolo import clip_augmented, descale_pred
+    rs = np.random.RandomState(4)
+    base = synth_pred(rs, 2, 1260, 3)
+    for flips, scale in ((None, 1.0), (3, 0.83), (2, 0.67), (None, 0.67)):
+        want = oy.descale_pred(T(base).clone(), flips, scale, (480, 640))
+        d = T(base).cuda()
+        v0 = d._version
+        got = descale_pred(d, flips, scale, (480, 640))
+        assert got is d and d._version > v0
+        np.testing.assert_array_equal(d.cpu().numpy(), want.numpy())
+    ys = [T(base), T(base[:, :900]), T(base[:, :400])]
+    want = oy.clip_augmented([y.clone() for y in ys], 3)
+    got = clip_augmented([y.cuda() for y in ys], 3)
+    for g, w in zip(got, want):
+        assert torch.equal(g.cpu(), w)
+    boxes = torch.rand(7, 4, device="cuda") * 900 - 100
+    v0 = boxes._version
+    clip_coords(boxes, (480, 640))
+    assert boxes._version > v0
