@@ -296,3 +296,17 @@ def test_evalmatch_oracle_vs_reference(golden, tag):
     cm.process_batch(det, lab)
     cm.process_batch(det[::2], lab)
     np.testing.assert_array_equal(cm.matrix, g[f"{tag}_matrix"])
+
+
+def test_tta_descale_and_clip_oracle_vs_reference(golden):
+    """Model._descale_pred (in-place branch) and _clip_augmented, models/yolo.py:155-183."""
+    from oracle import yolo as oy
+    g = golden("tta")
+    base = g["base"]
+    for k in range(4):
+        flips, scale = g[f"descale{k}_args"]
+        got = oy.descale_pred(torch.from_numpy(base.copy()), int(flips) or None, float(scale), (480, 640))
+        np.testing.assert_array_equal(got.numpy(), g[f"descale{k}"])
+    ys = oy.clip_augmented([torch.from_numpy(base), torch.from_numpy(base[:, :900]), torch.from_numpy(base[:, :400])], 3)
+    np.testing.assert_array_equal([y.shape[1] for y in ys], g["clip_shapes"])
+    np.testing.assert_array_equal(np.stack([ys[0][0, -1].numpy(), ys[-1][0, 0].numpy()]), g["clip_first_last"])

@@ -540,6 +540,31 @@ def gen_evalmatch(y_metrics):
     save("evalmatch", **out)
 
 
+def gen_tta():
+    """Model._descale_pred / _clip_augmented (models/yolo.py:155-183): models/yolo.py cannot be imported (model zoo,
+    network), so the two method definitions alone are compiled from the reference's file and called with a stand-in
+    for `self` that carries the two attributes they read."""
+    import ast
+    from types import SimpleNamespace
+    path = os.path.join(REF, "yolov5", "models", "yolo.py")
+    tree = ast.parse(open(path).read(), path)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Model"][0]
+    fns = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in ("_descale_pred", "_clip_augmented")]
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+    me = SimpleNamespace(inplace=True, model=[SimpleNamespace(nl=3)])
+    rs = np.random.RandomState(4)
+    base = synth_pred(rs, 2, 1260, 3)
+    out = {"base": base}
+    for k, (flips, scale) in enumerate(((None, 1.0), (3, 0.83), (2, 0.67), (None, 0.67))):
+        out[f"descale{k}"] = ns["_descale_pred"](me, T(base).clone(), flips, scale, (480, 640)).numpy()
+        out[f"descale{k}_args"] = np.array([0 if flips is None else flips, scale])
+    ys = ns["_clip_augmented"](me, [T(base), T(base[:, :900]), T(base[:, :400])])
+    out["clip_shapes"] = np.array([y.shape[1] for y in ys])
+    out["clip_first_last"] = np.stack([ys[0][0, -1].numpy(), ys[-1][0, 0].numpy()])
+    save("tta", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -553,6 +578,7 @@ def main():
     gen_nms(y_general)
     gen_centernet(a_loss, c_loss, c_data)
     gen_evalmatch(y_metrics)
+    gen_tta()
 
 
 if __name__ == "__main__":
