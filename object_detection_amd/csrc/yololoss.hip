@@ -419,7 +419,8 @@ extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int*
     int* invalid = (int*)(ws + W.off_invalid);
     hipStream_t st = (hipStream_t)stream;
     // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
-    if (hipMemsetAsync(owner, 0xFF, sizeof(int) * ((size_t)W.cells_total + 1), st) != hipSuccess) return DH_ERR_LAUNCH;
+    // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
+    if (hipMemsetAsync(owner, 0xFF, W.off_iou - W.off_owner, st) != hipSuccess) return DH_ERR_LAUNCH;
     if (cap > 0)
         hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
                            anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
