@@ -1,1 +1,6 @@
-for u in 2 4 8; do for n in 0 1 2 3; do echo -n "unroll=$u nt=$n: "; DH_DECODE_UNROLL=$u DH_DECODE_NT=$n timeout -k 10 120 python tools/time_kernels.py --only decode --iters 200 2>/dev/null | grep decode; done; done
+#!/bin/bash
+# Isolated decode timings over the tuning knobs of dh_yolo_decode (unroll factor, non-temporal policy:
+# bit 0 = loads, bit 1 = stores).
+for u in 2 4 8; do for n in 0 1 2 3; do
+  echo "unroll=$u nt=$n: $(DH_DECODE_UNROLL=$u DH_DECODE_NT=$n timeout -k 10 100 python tools/decode_variants.py 2>&1 | grep 'obj + logit')"
+done; done
