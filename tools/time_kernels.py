@@ -67,9 +67,19 @@ def main():
             torch.autograd.grad(loss, p)
         us2 = timed(fb, args.iters)
         print(f"assign+loss f+b   {us2:9.1f} us   bwd alone ~{us2 - us:8.1f} us  {348.0 * A * bs / (us2 - us) / 1e3:8.1f} GB/s (348 B/anchor)")
+    if "loss" in only:      # the training step: maps that no decode has read (no compact logit plane to borrow)
+        q = [x.detach().clone().requires_grad_(True) for x in levels]
+        us = timed(lambda: crit(q, targets), args.iters)
+        us2 = timed(lambda: crit.forward_backward(q, targets), args.iters)
+        print(f"training-only assign+loss fwd {us:9.1f} us   forward_backward {us2:9.1f} us")
+        del q
     if "nms" in only:
         us = timed(lambda: non_max_suppression(z, 0.25, 0.45, max_det=300), args.iters)
         print(f"nms 0.25/0.45     {us:9.1f} us")
+        zc = z.clone()      # a prediction tensor without the decode's compact objectness plane
+        us = timed(lambda: non_max_suppression(zc, 0.25, 0.45, max_det=300), args.iters)
+        print(f"nms 0.25/0.45 (strided objectness column) {us:9.1f} us")
+        del zc
         us = timed(lambda: non_max_suppression(z, 0.001, 0.6, multi_label=True, max_det=300), args.iters)
         print(f"nms 0.001/0.6 ml  {us:9.1f} us")
     if "centernet" in only:
