@@ -126,14 +126,16 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
     P.obj_plane = obj_plane;
     P.logit_plane = obj_logit_plane;
     const int vec = vec4 ? 4 : 1;
-    static int unroll = 0, nt = 0;
-    if (unroll == 0) {   // tuning knobs (defaults are the measured best)
+    // tuning knobs, read once (defaults are the measured best): unroll factor and non-temporal policy (bit 0 loads, bit 1 stores)
+    static const int unroll = [] {
         const char* u = getenv("DH_DECODE_UNROLL");
+        const int v = u ? atoi(u) : 8;
+        return (v == 2 || v == 4 || v == 8) ? v : 8;
+    }();
+    static const int nt = [] {
         const char* n = getenv("DH_DECODE_NT");
-        unroll = u ? atoi(u) : 8;
-        nt = n ? atoi(n) : 3;
-        if (unroll != 2 && unroll != 4 && unroll != 8) unroll = 8;
-    }
+        return n ? atoi(n) : 3;
+    }();
     const int per_block = 256 * (vec4 ? unroll : 4);
     uint32_t gx = 0;
     for (int l = 0; l < nl; ++l) {

@@ -94,17 +94,14 @@ def detect_decode(levels, anchors, stride):
         made_on = L.raw_stream()
         L.check(L.lib().dh_yolo_decode(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
                                        L.ptr(out), L.ptr(plane), L.ptr(logits), L.c_void_p(made_on)), "dh_yolo_decode")
-    if len(_OBJ_PLANES) > 8:
-        for k in [k for k, v in _OBJ_PLANES.items() if v[0]() is None]:
-            del _OBJ_PLANES[k]
-        if len(_OBJ_PLANES) > 8:
-            _OBJ_PLANES.clear()
+    # entries whose tensor has been freed go at once (they pin 8 bytes per anchor); the bound only guards against a
+    # caller that keeps every decoded tensor alive
+    for registry, dead in ((_OBJ_PLANES, lambda v: v[0]() is None), (_LOGIT_PLANES, lambda v: any(r() is None for r, _, _ in v[0]))):
+        for k in [k for k, v in registry.items() if dead(v)]:
+            del registry[k]
+        if len(registry) > 8:
+            registry.clear()
     _OBJ_PLANES[out.data_ptr()] = (weakref.ref(out), out._version, plane, made_on)
-    if len(_LOGIT_PLANES) > 8:
-        for k in [k for k, v in _LOGIT_PLANES.items() if any(r() is None for r, _, _ in v[0])]:
-            del _LOGIT_PLANES[k]
-        if len(_LOGIT_PLANES) > 8:
-            _LOGIT_PLANES.clear()
     _LOGIT_PLANES[xs[0].data_ptr()] = ([(weakref.ref(x), x._version, tuple(x.shape)) for x in xs], logits, made_on)
     return out
 
