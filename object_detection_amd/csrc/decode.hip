@@ -27,9 +27,13 @@ struct decode_params {
 
 // One block owns DH_DEC_UNROLL*256 consecutive vectors of ONE level of ONE image, so the level
 // record is wave-uniform (scalar registers).  VEC = 4 needs every level span to be a multiple of
-// 4 floats and 16-byte aligned; VEC = 1 is the general fallback.  Every element gets its sigmoid
-// unconditionally; the 4-of-`no` box channels are patched afterwards, once per vector, so the hot
-// path has a single division by `no` and one (rarely taken) branch per 16 bytes.
+// 4 floats and 16-byte aligned, and no >= 7 (a vector then touches the box channels of at most one
+// row); VEC = 1 is the general fallback.  Every element gets its sigmoid unconditionally; a vector
+// that holds box channels patches them afterwards.  A wave's 256 consecutive floats always contain
+// some row's box, so that patch runs in every wave for a few lanes: it is kept short (the row is
+// decomposed once per vector, not once per element) and free of memory instructions (the level
+// record is read into scalar registers up front), so the loads already in flight are never waited for.
+#define DH_PIN_SGPR(v) asm volatile("" : "+s"(v))
 template <int VEC, int DH_DEC_UNROLL, int NT>
 __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, float* __restrict__ out)
 {
@@ -47,6 +51,14 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
     float* __restrict__ dst = out + (size_t)b * P.per_image + L.first;
     const uint32_t v0 = blk * (256 * DH_DEC_UNROLL) + threadIdx.x;
     if (VEC == 4) {
+        dh_fastdiv plane = L.plane, nxd = L.nx;
+        uint32_t stride_bits = __float_as_uint(L.stride);
+        uint32_t anc[2 * DH_MAX_ANCHORS];
+#pragma unroll
+        for (int q = 0; q < 2 * DH_MAX_ANCHORS; ++q) { anc[q] = __float_as_uint(L.anchor_px[q]); DH_PIN_SGPR(anc[q]); }
+        DH_PIN_SGPR(plane.magic); DH_PIN_SGPR(plane.shift); DH_PIN_SGPR(plane.d);
+        DH_PIN_SGPR(nxd.magic); DH_PIN_SGPR(nxd.shift); DH_PIN_SGPR(nxd.d); DH_PIN_SGPR(stride_bits);
+        const float stride = __uint_as_float(stride_bits);
         dh_f4 x[DH_DEC_UNROLL];
 #pragma unroll
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
@@ -64,12 +76,27 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
             float y[4] = {dh_sigmoid(x[u].x), dh_sigmoid(x[u].y), dh_sigmoid(x[u].z), dh_sigmoid(x[u].w)};
             const uint32_t row = dh_div(e, P.no);
             const uint32_t c0 = e - row * no;
-            if (c0 < 4 || c0 + 3 >= no) {           // the vector touches box channels of `row` or of `row + 1`
+            if (c0 < 4 || c0 + 3 >= no) {           // the vector touches box channels of `row` or of `row + 1` (never both)
+                const bool next = c0 >= 4;
+                const uint32_t r = row + (next ? 1u : 0u);
+                const int k0 = next ? (int)(no - c0) : -(int)c0;      // element of this vector where channel 0 of row r sits
+                const uint32_t a = dh_div(r, plane);
+                const uint32_t cell = r - a * plane.d;
+                const uint32_t gy = dh_div(cell, nxd);
+                const uint32_t gx = cell - gy * nxd.d;
+                uint32_t aw = anc[0], ah = anc[1];
+#pragma unroll
+                for (int q = 1; q < DH_MAX_ANCHORS; ++q)
+                    if (a == (uint32_t)q) { aw = anc[2 * q]; ah = anc[2 * q + 1]; }
+                const float fgx = (float)gx, fgy = (float)gy;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    uint32_t c = c0 + k, r = row;
-                    if (c >= no) { c -= no; r += 1; }
-                    if (c < 4) y[k] = decode_box(L, r, c, y[k]);
+                    const int c = k - k0;
+                    const float sv = y[k];
+                    const float xy = (sv * 2.0f - 0.5f + ((c & 1) ? fgy : fgx)) * stride;     // yolo.py:60,66
+                    const float t = sv * 2.0f;
+                    const float wh = (t * t) * __uint_as_float((c & 1) ? ah : aw);            // yolo.py:61,67
+                    if (c >= 0 && c < 4) y[k] = c < 2 ? xy : wh;
                 }
             }
             if (P.obj_plane) {       // channel 4 of `row` sits at offset 4 - c0, of `row + 1` at 4 - c0 + no
@@ -121,7 +148,7 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
     bool vec4 = false;
     if (!dh_make_levels(level_ptrs, ny, nx, nl, na, no, anchor_px, strides, P.lvl, &P.per_image, &P.rows_per_image, &vec4))
         return DH_ERR_ARG;
-    vec4 = vec4 && dh_aligned16(out);
+    vec4 = vec4 && dh_aligned16(out) && no >= 7;
     if (obj_logit_plane && !obj_plane) return DH_ERR_ARG;   // the logit copy rides on the objectness-plane path
     P.obj_plane = obj_plane;
     P.logit_plane = obj_logit_plane;
@@ -129,8 +156,8 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
     // tuning knobs, read once (defaults are the measured best): unroll factor and non-temporal policy (bit 0 loads, bit 1 stores)
     static const int unroll = [] {
         const char* u = getenv("DH_DECODE_UNROLL");
-        const int v = u ? atoi(u) : 8;
-        return (v == 2 || v == 4 || v == 8) ? v : 8;
+        const int v = u ? atoi(u) : 2;
+        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 2;
     }();
     static const int nt = [] {
         const char* n = getenv("DH_DECODE_NT");
@@ -147,7 +174,7 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
 #define DH_DEC(U, N) hipLaunchKernelGGL((k_yolo_decode<4, U, N>), dim3(gx, bs), dim3(256), 0, st, P, out)
 #define DH_DEC_NT(U) do { if (nt == 0) DH_DEC(U, 0); else if (nt == 1) DH_DEC(U, 1); else if (nt == 2) DH_DEC(U, 2); else DH_DEC(U, 3); } while (0)
     if (vec4) {
-        if (unroll == 2) DH_DEC_NT(2); else if (unroll == 8) DH_DEC_NT(8); else DH_DEC_NT(4);
+        if (unroll == 1) DH_DEC_NT(1); else if (unroll == 2) DH_DEC_NT(2); else if (unroll == 8) DH_DEC_NT(8); else DH_DEC_NT(4);
     } else {
         hipLaunchKernelGGL((k_yolo_decode<1, 4, 0>), dim3(gx, bs), dim3(256), 0, st, P, out);
     }
