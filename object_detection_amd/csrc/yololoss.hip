@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, c
 
 // ------------------------------------------------------------------------------------ backward: dense pass
 // Writes every element of the gradient once: zero everywhere except the objectness channel.
-#define GRAD_VEC_PER_BLOCK 1024
+#define GRAD_VEC_PER_BLOCK 256
 
 template <int VEC>
 __global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const float* __restrict__ dobj,
