@@ -168,6 +168,18 @@ int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl
                      int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_p,
                      const void* workspace, size_t workspace_bytes, void* stream);
 
+/* dh_build_targets + dh_yolo_loss_fwd + dh_yolo_loss_bwd as one sequence of five launches (a training step's
+ * `loss = compute_loss(pred, targets); loss.backward()`, object_detection/yolov5/train.py:329,337, when the caller
+ * takes the gradients directly): the owner-map fill rides in spare workgroups of the assignment launch and the
+ * forward's final reduction in workgroup 0 of the dense gradient launch, so neither costs a launch of its own.
+ * Arguments as in the three entries; idx/tbox/anch/tcls/counts are outputs (the assignment), assign_workspace is
+ * dh_build_targets_workspace bytes, workspace dh_yolo_loss_workspace bytes.  out and grad_p as in the separate calls. */
+int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const float* anchors, double anchor_t, const float* const* p,
+                         const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t* idx, float* tbox, float* anch,
+                         int64_t* tcls, int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits,
+                         const float* grad_loss, float* const* grad_p, float* out, void* assign_workspace,
+                         size_t assign_workspace_bytes, void* workspace, size_t workspace_bytes, void* stream);
+
 /* N x M IoU of xyxy boxes, no eps (object_detection/yolov5/utils/metrics.py:242-264) and of
  * (w,h) pairs (metrics.py:291-296).  out is (N,M) row-major. */
 int dh_box_iou(const float* box1, const float* box2, float* out, int64_t N, int64_t M, void* stream);

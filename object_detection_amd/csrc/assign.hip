@@ -10,6 +10,7 @@
 // order-preserving ballot/prefix-scan compaction (no atomics), one workgroup per level.
 // The clamp of loss.py:217 works in place on views of the cell tensor, so tbox uses clamped cells.
 #include "dh_common.h"
+#include "dh_internal.h"
 #include "../../include/dethead.h"
 
 namespace {
@@ -55,9 +56,16 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
                                                               const float* __restrict__ anchors, const bt_params P,
                                                               int* __restrict__ list_ws, long long* __restrict__ idx,
                                                               float* __restrict__ tbox, float* __restrict__ anch,
-                                                              long long* __restrict__ tcls, int* __restrict__ counts)
+                                                              long long* __restrict__ tcls, int* __restrict__ counts,
+                                                              uint4* __restrict__ fill, size_t fill_vecs)
 {
     __shared__ int s_w[BT_THREADS / 64];
+    if ((int)blockIdx.x >= P.nl) {      // side duty of the same launch: set a caller's region to all ones (16 B per store)
+        const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        const size_t step = (size_t)(gridDim.x - P.nl) * BT_THREADS;
+        for (size_t i = (size_t)(blockIdx.x - P.nl) * BT_THREADS + threadIdx.x; i < fill_vecs; i += step) fill[i] = ones;
+        return;
+    }
     const int l = blockIdx.x;
     const int nx = P.nx[l], ny = P.ny[l];
     const float fnx = (float)nx, fny = (float)ny;
@@ -146,14 +154,20 @@ extern "C" size_t dh_build_targets_workspace(int nl, int na, int64_t nt)
     return (size_t)nl * na * nt * sizeof(int) + 256;
 }
 
-extern "C" int dh_build_targets(const float* targets, int64_t nt, const float* anchors, int nl, int na, const int* ny,
-                                const int* nx, double anchor_t, int64_t cap, int64_t* idx, float* tbox, float* anch,
-                                int64_t* tcls, int* counts, void* workspace, size_t workspace_bytes, void* stream)
+// Shared by dh_build_targets and the fused loss entry: the assignment launch, which can also fill `fill_bytes`
+// (a multiple of 16, 16-byte aligned) at `fill` with 0xFF in spare workgroups of the same launch.
+int dh_launch_build_targets(const float* targets, int64_t nt, const float* anchors, int nl, int na, const int* ny, const int* nx,
+                            double anchor_t, int64_t cap, int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts,
+                            void* workspace, size_t workspace_bytes, void* fill, size_t fill_bytes, void* stream)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || nt < 0 || !ny || !nx || !counts || !anchors) return DH_ERR_ARG;
     if ((long long)na * nt >= (1ll << 30)) return DH_ERR_ARG;
+    if (fill_bytes && (!fill || (fill_bytes & 15u) || !dh_aligned16(fill))) return DH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (nt == 0) return hipMemsetAsync(counts, 0, sizeof(int) * nl, st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (nt == 0) {
+        if (fill_bytes && hipMemsetAsync(fill, 0xFF, fill_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
+        return hipMemsetAsync(counts, 0, sizeof(int) * nl, st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    }
     if (!targets || !idx || !tbox || !anch || !tcls || !workspace || cap < 5ll * na * nt) return DH_ERR_ARG;
     if (workspace_bytes < dh_build_targets_workspace(nl, na, nt)) return DH_ERR_WORKSPACE;
     bt_params P;
@@ -163,7 +177,19 @@ extern "C" int dh_build_targets(const float* targets, int64_t nt, const float* a
         P.nx[l] = nx[l];
     }
     P.nl = nl; P.na = na; P.nt = (int)nt; P.anchor_t = (float)anchor_t; P.cap = (long)cap;
-    hipLaunchKernelGGL(k_build_targets, dim3(nl), dim3(BT_THREADS), 0, st, targets, anchors, P, (int*)workspace,
-                       (long long*)idx, tbox, anch, (long long*)tcls, counts);
+    const size_t fill_vecs = fill_bytes / 16;
+    // 32 KiB of fill per spare workgroup (two stores per thread), at most 512 of them
+    size_t spare = (fill_vecs + 2 * BT_THREADS - 1) / (2 * BT_THREADS);
+    if (spare > 512) spare = 512;
+    hipLaunchKernelGGL(k_build_targets, dim3(nl + (unsigned)spare), dim3(BT_THREADS), 0, st, targets, anchors, P, (int*)workspace,
+                       (long long*)idx, tbox, anch, (long long*)tcls, counts, (uint4*)fill, fill_vecs);
     return dh_launch_status();
+}
+
+extern "C" int dh_build_targets(const float* targets, int64_t nt, const float* anchors, int nl, int na, const int* ny,
+                                const int* nx, double anchor_t, int64_t cap, int64_t* idx, float* tbox, float* anch,
+                                int64_t* tcls, int* counts, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return dh_launch_build_targets(targets, nt, anchors, nl, na, ny, nx, anchor_t, cap, idx, tbox, anch, tcls, counts, workspace,
+                                   workspace_bytes, nullptr, 0, stream);
 }

@@ -14,6 +14,7 @@
 // the strided logits.  Backward = 2 launches: one streaming pass writes the whole dense gradient (zeros +
 // scaled objectness term, 16-byte stores), then the positive rows add their box / class terms.
 #include "dh_iou.h"
+#include "dh_internal.h"
 #include "../../include/dethead.h"
 
 namespace {
@@ -26,7 +27,8 @@ struct yl_level {
     long cell_first;     // offset of this level in the owner map
     dh_fastdiv per_image;   // na*ny*nx
     uint32_t row_first;  // first row of this level inside one image of the decoded (bs, A) planes
-    unsigned blocks;     // dense-pass blocks of this level
+    unsigned blocks;     // dense-pass blocks of this level (forward: objectness blocks, backward: gradient blocks)
+    unsigned fwd_blocks; // objectness-pass blocks of this level: one partial sum each
     float balance;
 };
 
@@ -191,23 +193,24 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
 //      [5..5+nl) mean objectness BCE per level, [5+nl] ignored rows
 #define FINAL_THREADS 1024
 
-__global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, const int* __restrict__ counts,
-                                                            const float* __restrict__ iou_ws, const float* __restrict__ cls_ws,
-                                                            const double* __restrict__ partial, const int* __restrict__ invalid,
-                                                            float* __restrict__ out)
+// the reduction proper, run by THREADS threads of one workgroup
+template <int THREADS>
+__device__ __forceinline__ void yl_finalize(const yl_params& P, const int* __restrict__ counts, const float* __restrict__ iou_ws,
+                                            const float* __restrict__ cls_ws, const double* __restrict__ partial,
+                                            const int* __restrict__ invalid, float* __restrict__ out,
+                                            double (*red)[THREADS / 64])
 {
-    __shared__ double red[3 * DH_MAX_LEVELS][FINAL_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned first_block = 0;
     for (int l = 0; l < P.nl; ++l) {       // all loads of all levels are independent: no barrier inside the loop
         const int n = counts[l];
         double sb = 0.0, sc = 0.0, so = 0.0;
-        for (int r = threadIdx.x; r < n; r += FINAL_THREADS) {
+        for (int r = threadIdx.x; r < n; r += THREADS) {
             sb += (double)(1.0f - iou_ws[(size_t)l * P.cap + r]);
             sc += (double)cls_ws[(size_t)l * P.cap + r];
         }
-        for (unsigned k = threadIdx.x; k < P.lvl[l].blocks; k += FINAL_THREADS) so += partial[first_block + k];
-        first_block += P.lvl[l].blocks;
+        for (unsigned k = threadIdx.x; k < P.lvl[l].fwd_blocks; k += THREADS) so += partial[first_block + k];
+        first_block += P.lvl[l].fwd_blocks;
         sb = dh_wave_sum_d(sb); sc = dh_wave_sum_d(sc); so = dh_wave_sum_d(so);
         if (lane == 0) { red[3 * l + 0][wave] = sb; red[3 * l + 1][wave] = sc; red[3 * l + 2][wave] = so; }
     }
@@ -218,7 +221,7 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, c
         for (int l = 0; l < P.nl; ++l) {
             n_pos += counts[l];
             double tb = 0.0, tc = 0.0, to = 0.0;
-            for (int w = 0; w < FINAL_THREADS / 64; ++w) { tb += red[3 * l][w]; tc += red[3 * l + 1][w]; to += red[3 * l + 2][w]; }
+            for (int w = 0; w < THREADS / 64; ++w) { tb += red[3 * l][w]; tc += red[3 * l + 1][w]; to += red[3 * l + 2][w]; }
             const int n = counts[l];
             const float s_box = n > 0 ? (float)(tb / n) : 0.0f;
             const float s_cls = (n > 0 && P.nc > 1) ? (float)(tc / ((double)n * P.nc)) : 0.0f;
@@ -236,14 +239,39 @@ __global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, c
     }
 }
 
+__global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, const int* __restrict__ counts,
+                                                            const float* __restrict__ iou_ws, const float* __restrict__ cls_ws,
+                                                            const double* __restrict__ partial, const int* __restrict__ invalid,
+                                                            float* __restrict__ out)
+{
+    __shared__ double red[3 * DH_MAX_LEVELS][FINAL_THREADS / 64];
+    yl_finalize<FINAL_THREADS>(P, counts, iou_ws, cls_ws, partial, invalid, out, red);
+}
+
 // ------------------------------------------------------------------------------------ backward: dense pass
 // Writes every element of the gradient once: zero everywhere except the objectness channel.
 #define GRAD_VEC_PER_BLOCK 256
 
-template <int VEC>
+// FINAL: workgroup 0 also reduces the forward's partial sums into `out` (the fused forward+backward entry: the
+// reduction then costs nothing, hidden under this bandwidth-bound launch, instead of a launch of its own).
+struct yl_final_args {
+    const int* counts;
+    const float* iou_ws;
+    const float* cls_ws;
+    const double* partial;
+    const int* invalid;
+    float* out;
+};
+
+template <int VEC, bool FINAL>
 __global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const float* __restrict__ dobj,
-                                                    const float* __restrict__ g_loss, const dh_fastdiv nod)
+                                                    const float* __restrict__ g_loss, const dh_fastdiv nod,
+                                                    const yl_final_args F)
 {
+    if (FINAL && blockIdx.x == 0) {
+        __shared__ double red[3 * DH_MAX_LEVELS][4];
+        yl_finalize<256>(P, F.counts, F.iou_ws, F.cls_ws, F.partial, F.invalid, F.out, red);
+    }
     unsigned blk = blockIdx.x;
     const int l = level_of_block(P, blk);
     const yl_level& L = P.lvl[l];
@@ -355,6 +383,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
         if ((unsigned long long)L.cells * P.no >= (1ull << 32)) return false;
         L.cell_first = first;
         first += L.cells;
+        L.fwd_blocks = (unsigned)((L.cells + OBJ_CELLS_PER_BLOCK - 1) / OBJ_CELLS_PER_BLOCK);
         if (grad_blocks) {
             const size_t total = (size_t)L.cells * P.no;
             const size_t nvec = (total % 4 == 0) ? total / 4 : total;
@@ -400,6 +429,63 @@ extern "C" size_t dh_yolo_loss_workspace(const int* ny, const int* nx, int nl, i
     return W.total;
 }
 
+namespace {
+
+// forward launches; fill: set the owner map (and the two counters behind it) to -1 here, false when the caller's
+// assignment launch already did; final: run the reduction as a launch of its own
+int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx, const float* tbox, const float* anch,
+               const int64_t* tcls, const int* counts, const float* obj_logits, float* out, bool fill, bool final, hipStream_t st)
+{
+    int* owner = (int*)(ws + W.off_owner);
+    float* iou_ws = (float*)(ws + W.off_iou);
+    float* cls_ws = (float*)(ws + W.off_cls);
+    double* partial = (double*)(ws + W.off_partial);
+    int* invalid = (int*)(ws + W.off_invalid);
+    // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
+    // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
+    if (fill && hipMemsetAsync(owner, 0xFF, W.off_iou - W.off_owner, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (P.cap > 0)
+        hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
+                           anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+    hipLaunchKernelGGL(k_yl_obj_fwd, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
+                       (float*)(ws + W.off_dobj), obj_logits);
+    if (final)
+        hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(FINAL_THREADS), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
+    return dh_launch_status();
+}
+
+// backward launches; F != nullptr: workgroup 0 of the dense pass also reduces the forward's partial sums into F->out
+int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx, const float* tbox, const float* anch,
+               const int64_t* tcls, const int* counts, const float* grad_loss, float* const* grad_p, const yl_final_args* F,
+               hipStream_t st)
+{
+    bool vec4 = true;
+    for (int l = 0; l < P.nl; ++l) vec4 = vec4 && ((size_t)P.lvl[l].cells * P.no) % 4 == 0 && dh_aligned16(grad_p[l]);
+    if (!vec4) {   // scalar stores: one element per "vector"
+        for (int l = 0; l < P.nl; ++l) {
+            const size_t total = (size_t)P.lvl[l].cells * P.no;
+            P.lvl[l].blocks = (unsigned)((total + GRAD_VEC_PER_BLOCK - 1) / GRAD_VEC_PER_BLOCK);
+        }
+    }
+    const float* dobj = (const float*)(ws + W.off_dobj);
+    const dh_fastdiv nod = dh_make_fastdiv((uint32_t)P.no);
+    const yl_final_args none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const dim3 grid(sum_blocks(P));
+    if (F) {
+        if (vec4) hipLaunchKernelGGL((k_yl_obj_bwd<4, true>), grid, dim3(256), 0, st, P, dobj, grad_loss, nod, *F);
+        else hipLaunchKernelGGL((k_yl_obj_bwd<1, true>), grid, dim3(256), 0, st, P, dobj, grad_loss, nod, *F);
+    } else {
+        if (vec4) hipLaunchKernelGGL((k_yl_obj_bwd<4, false>), grid, dim3(256), 0, st, P, dobj, grad_loss, nod, none);
+        else hipLaunchKernelGGL((k_yl_obj_bwd<1, false>), grid, dim3(256), 0, st, P, dobj, grad_loss, nod, none);
+    }
+    if (P.cap > 0)
+        hipLaunchKernelGGL(k_yl_pos_bwd, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
+                           anch, (const long long*)tcls, counts, grad_loss);
+    return dh_launch_status();
+}
+
+}  // namespace
+
 extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                                 const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
                                 const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out,
@@ -413,23 +499,7 @@ extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int*
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && !dh_aligned16(tbox))) return DH_ERR_ALIGN;
-    char* ws = (char*)workspace;
-    int* owner = (int*)(ws + W.off_owner);
-    float* iou_ws = (float*)(ws + W.off_iou);
-    float* cls_ws = (float*)(ws + W.off_cls);
-    double* partial = (double*)(ws + W.off_partial);
-    int* invalid = (int*)(ws + W.off_invalid);
-    hipStream_t st = (hipStream_t)stream;
-    // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
-    // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
-    if (hipMemsetAsync(owner, 0xFF, W.off_iou - W.off_owner, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (cap > 0)
-        hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
-                           anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
-    hipLaunchKernelGGL(k_yl_obj_fwd, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
-                       (float*)(ws + W.off_dobj), obj_logits);
-    hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(FINAL_THREADS), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
-    return dh_launch_status();
+    return launch_fwd(P, W, (char*)workspace, idx, tbox, anch, tcls, counts, obj_logits, out, true, true, (hipStream_t)stream);
 }
 
 extern "C" int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
@@ -441,27 +511,38 @@ extern "C" int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int*
     yl_ws W;
     if (!p || !grad_p || !hyp || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
     if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, P, W)) return DH_ERR_ARG;
-    bool vec4 = true;
-    for (int l = 0; l < nl; ++l) {
-        if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
-        vec4 = vec4 && ((size_t)P.lvl[l].cells * P.no) % 4 == 0 && dh_aligned16(grad_p[l]);
-    }
-    if (!vec4) {   // scalar stores: one element per "vector"
-        for (int l = 0; l < nl; ++l) {
-            const size_t total = (size_t)P.lvl[l].cells * P.no;
-            P.lvl[l].blocks = (unsigned)((total + GRAD_VEC_PER_BLOCK - 1) / GRAD_VEC_PER_BLOCK);
-        }
-    }
+    for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
-    const char* ws = (const char*)workspace;
-    const float* dobj = (const float*)(ws + W.off_dobj);
-    hipStream_t st = (hipStream_t)stream;
-    const dh_fastdiv nod = dh_make_fastdiv((uint32_t)P.no);
-    if (vec4) hipLaunchKernelGGL(k_yl_obj_bwd<4>, dim3(sum_blocks(P)), dim3(256), 0, st, P, dobj, grad_loss, nod);
-    else hipLaunchKernelGGL(k_yl_obj_bwd<1>, dim3(sum_blocks(P)), dim3(256), 0, st, P, dobj, grad_loss, nod);
-    if (cap > 0)
-        hipLaunchKernelGGL(k_yl_pos_bwd, dim3((unsigned)((cap + 3) / 4), nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
-                           anch, (const long long*)tcls, counts, grad_loss);
-    return dh_launch_status();
+    return launch_bwd(P, W, (const char*)workspace, idx, tbox, anch, tcls, counts, grad_loss, grad_p, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const float* anchors, double anchor_t,
+                                    const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                    int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
+                                    const dh_yolo_hyp* hyp, const float* obj_logits, const float* grad_loss,
+                                    float* const* grad_p, float* out, void* assign_workspace, size_t assign_workspace_bytes,
+                                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    yl_params P, Pb;
+    yl_ws W, Wb;
+    if (!p || !grad_p || !hyp || !out || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
+    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W)) return DH_ERR_ARG;
+    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, Pb, Wb)) return DH_ERR_ARG;
+    for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
+    if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
+    if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && !dh_aligned16(tbox))) return DH_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    // 1 assignment; spare workgroups of that launch set the owner map and the counters behind it to -1
+    int rc = dh_launch_build_targets(targets, nt, anchors, nl, na, ny, nx, anchor_t, cap, idx, tbox, anch, tcls, counts,
+                                     assign_workspace, assign_workspace_bytes, ws + W.off_owner, W.off_iou - W.off_owner, stream);
+    if (rc != DH_OK) return rc;
+    // 2 positives, 3 dense objectness (no reduction launch)
+    rc = launch_fwd(P, W, ws, idx, tbox, anch, tcls, counts, obj_logits, out, false, false, (hipStream_t)stream);
+    if (rc != DH_OK) return rc;
+    // 4 dense gradient, whose workgroup 0 also does the forward's reduction, 5 positives' gradient
+    const yl_final_args F = {counts, (const float*)(ws + W.off_iou), (const float*)(ws + W.off_cls),
+                             (const double*)(ws + W.off_partial), (const int*)(ws + W.off_invalid), out};
+    return launch_bwd(Pb, Wb, ws, idx, tbox, anch, tcls, counts, grad_loss, grad_p, &F, (hipStream_t)stream);
 }

@@ -114,6 +114,39 @@ def _one(device):
     return hit
 
 
+def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss):
+    """Assignment, loss forward and backward through the single fused entry; returns (assignment, out, grads)."""
+    tg = L.dev_f32(targets, "targets").contiguous()
+    if tg.dim() != 2 or tg.shape[1] != 6:
+        raise RuntimeError(f"targets must be (nt,6) [image,class,x,y,w,h], got {tuple(targets.shape)}")
+    anc = L.dev_f32(anchors, "anchors").contiguous()
+    nl, na = int(anc.shape[0]), int(anc.shape[1])
+    dev = maps[0].device
+    A = _Assignment(shapes, tg.shape[0], na, nl, dev)
+    bs = int(maps[0].shape[0])
+    for x, ny_, nx_ in zip(maps, A.ny, A.nx):
+        if tuple(x.shape) != (bs, na, ny_, nx_, nc + 5):
+            raise RuntimeError(f"ComputeLoss: level shape {tuple(x.shape)} does not match (bs,na,ny,nx,5+nc)")
+    lib = L.lib()
+    ny, nx = L.int_array(A.ny), L.int_array(A.nx)
+    aws_bytes = lib.dh_build_targets_workspace(nl, na, A.nt)
+    ws_bytes = lib.dh_yolo_loss_workspace(ny, nx, nl, bs, na, nc, A.cap)
+    if ws_bytes == 0:
+        raise RuntimeError("ComputeLoss: unsupported problem size (a level exceeds 2^32 elements)")
+    aws, ws = L.workspace(aws_bytes, dev), L.workspace(ws_bytes, dev)
+    out = torch.empty(6 + nl, dtype=torch.float32, device=dev)
+    grads = [torch.empty_like(x) for x in maps]
+    ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
+    gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
+    logits = objectness_logits(maps)
+    with L.device_guard(dev):
+        L.check(lib.dh_yolo_loss_fwd_bwd(L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc,
+                                         L.ptr(A.idx), L.ptr(A.tbox), L.ptr(A.anch), L.ptr(A.tcls), L.ptr(A.counts), A.cap,
+                                         ctypes.byref(hyp), L.ptr(logits), L.ptr(grad_loss), gptrs, L.ptr(out), L.ptr(aws),
+                                         aws_bytes, L.ptr(ws), ws_bytes, L.stream()), "dh_yolo_loss_fwd_bwd")
+    return A, out, grads
+
+
 class _YoloLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, assign, hyp, nc, *p):
@@ -199,21 +232,25 @@ class ComputeLoss:
     def forward_backward(self, p, targets, grad_loss=None, assignment=None):
         """Loss and its gradients in one call, without the autograd engine: (loss[1], loss_items[3], [dL/dp_i]).
 
-        Same kernels as __call__ followed by backward(); grad_loss (1 float on the device, default 1) is the
-        upstream gradient of the loss.  Everything stays on the calling stream with no host synchronisation,
-        which makes the call safe to capture in a HIP graph (the autograd engine's cross-stream bookkeeping is not).
+        The arithmetic of __call__ followed by backward() in five launches instead of nine; grad_loss (1 float on
+        the device, default 1) is the upstream gradient of the loss.  Everything stays on the calling stream with no
+        host synchronisation and no hop to the autograd engine's device thread.
         """
         if self.sort_obj_iou or self.autobalance:
             raise NotImplementedError("forward_backward supports neither sort_obj_iou nor autobalance")
         maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
         shapes = [(int(x.shape[2]), int(x.shape[3])) for x in maps]
-        assign = self._assignment_for(shapes, targets, assignment)
-        self.last_positive_counts = assign.counts
         hyp = self._hyp_struct()
-        out, ws = _loss_fwd(assign, hyp, int(self.nc), maps)
         if grad_loss is None:
             grad_loss = _one(maps[0].device)
-        grads = _loss_bwd(assign, hyp, int(self.nc), maps, ws, grad_loss.reshape(1).float().contiguous())
+        grad_loss = grad_loss.reshape(1).float().contiguous()
+        if assignment is not None:      # an assignment made earlier (possibly on another stream): the separate entries
+            assign = self._assignment_for(shapes, targets, assignment)
+            out, ws = _loss_fwd(assign, hyp, int(self.nc), maps)
+            grads = _loss_bwd(assign, hyp, int(self.nc), maps, ws, grad_loss)
+        else:
+            assign, out, grads = _loss_fused(shapes, targets, self.anchors, self.hyp['anchor_t'], hyp, int(self.nc), maps, grad_loss)
+        self.last_positive_counts = assign.counts
         self.last_stats = out[1:5]
         return out[0:1], out[1:4], grads
 

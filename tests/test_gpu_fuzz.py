@@ -172,6 +172,7 @@ def test_compute_loss_fuzz(seed):
     fl, fi, fg = crit.forward_backward(d, T(targets).cuda(), grad_loss=torch.tensor([up], device="cuda"))
     # same kernels without the autograd engine; cells that several rows share add their terms with float atomics, whose
     # order is not fixed, so the last bits may differ between two runs
-    assert torch.equal(fl, gl.detach()) and torch.equal(fi, gi)
+    close(fl, gl.detach(), rtol=1e-6)       # (the final reduction runs with another workgroup size: fp64 partial sums regroup)
+    close(fi, gi, rtol=1e-6)
     for a, b in zip(fg, gg):
         close(a, b, rtol=1e-6)

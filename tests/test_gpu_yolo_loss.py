@@ -152,7 +152,14 @@ def test_full_size_bs64_640_pipeline_vs_oracle():
     close(gi, wi)
     for a, b in zip(gg, wg):
         close(a, b)
-    del gg, wg
+    # the fused forward+backward entry (five launches) against the same oracle values
+    fl, fi, fg = crit.forward_backward(d, T(targets).cuda())
+    close(fl, wl.detach())
+    close(fi, wi)
+    for a, b in zip(fg, wg):
+        close(a, b)
+    assert int(crit.last_stats[3].item()) == sum(int(c) for c in crit.last_positive_counts.tolist()) > 3000
+    del gg, wg, fg
     wz = oy.detect_decode([T(x) for x in levels], anchors, oy.YOLOV5S_STRIDES)
     gz = detect_decode([x.detach() for x in d], anchors.cuda(), torch.tensor(oy.YOLOV5S_STRIDES))
     close(gz, wz)
