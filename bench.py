@@ -173,7 +173,6 @@ def main():
     strides = torch.tensor([float(s) for s in STRIDES])
     A = sum(3 * (img // s) ** 2 for s in STRIDES)
     p = [x.requires_grad_(True) for x in levels]
-    level_shapes = [(int(x.shape[2]), int(x.shape[3])) for x in levels]
 
     from object_detection_amd.general import nms_launch, nms_meta_to_host, nms_views, non_max_suppression
     stages = ("decode", "assign+loss_fwd+bwd", "nms", "d2h")
@@ -184,11 +183,11 @@ def main():
         with torch.no_grad():
             return detect_decode(levels, anchors, strides)
 
-    def f_loss(assignment=None):
-        if not args.autograd:      # the fused forward+backward entry: same kernels, no autograd-engine thread hop
-            loss, items, grads = crit.forward_backward(p, targets, assignment=assignment)
+    def f_loss():
+        if not args.autograd:      # the fused forward+backward entry: five launches, no autograd-engine thread hop
+            loss, items, grads = crit.forward_backward(p, targets)
         else:
-            loss, items = crit(p, targets, assignment=assignment)
+            loss, items = crit(p, targets)
             grads = torch.autograd.grad(loss, p)
         return loss, items, grads, crit.last_stats       # [lbox, lobj, lcls, n_pos], written by the loss kernel
 
@@ -205,22 +204,16 @@ def main():
     nms_stream = torch.cuda.Stream() if overlap else main_stream
     loss_stream = torch.cuda.Stream() if n_streams == 3 else main_stream
     set_stream = torch.cuda.set_stream
-    assign_early = overlap and os.environ.get("DH_BENCH_ASSIGN_EARLY", "0") == "1"
 
     def launch(record, detail=False):
         """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation.
         record: bracket the decode launch with timing events (every timed step); detail: also the other stages
-        (every 4th timed step: each event is a marker packet in the queue and costs host time, too)."""
+        (every 4th timed step: each event is a marker packet in the queue and costs host time, too).
+        The loss is enqueued before the NMS chain: it continues the critical (main) stream, the NMS chain only has to
+        be done by the time its step is finished one iteration later."""
         marks = mark_pool.pop() if record else None
         detail = detail and record
         h0 = time.perf_counter()
-        assignment = None
-        if assign_early:      # target assignment needs only the targets: enqueue it beside the decode
-            set_stream(nms_stream)
-            assignment = crit.assign(level_shapes, targets)
-            assigned = torch.cuda.Event()
-            assigned.record()
-            set_stream(main_stream)
         if record: marks[0].record()
         z = f_decode()
         if record: marks[1].record()
@@ -228,39 +221,36 @@ def main():
         if overlap:
             decoded = torch.cuda.Event()
             decoded.record()
-            nms_stream.wait_event(decoded)
             if n_streams == 3:
                 loss_stream.wait_event(decoded)
+                set_stream(loss_stream)
+        if detail: marks[6].record()
+        loss, items, grads, stats = f_loss()
+        if detail: marks[2].record()
+        h2 = time.perf_counter()
+        if overlap:
+            if world > 1:      # the collective waits for the loss on the side stream: the next decode does not wait for the other ranks
+                reduced_after = torch.cuda.Event()
+                reduced_after.record()
+            nms_stream.wait_event(decoded)
             set_stream(nms_stream)
         if detail: marks[3].record()
         rows, meta, _ = nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
         if detail: marks[4].record()
         host_meta, copied = nms_meta_to_host(meta)           # the step's only device-to-host copy (4*bs ints)
         if detail: marks[5].record()
-        h2 = time.perf_counter()
-        if overlap:
-            set_stream(loss_stream)
-            if assign_early:
-                loss_stream.wait_event(assigned)
-        if detail: marks[6].record()
-        loss, items, grads, stats = f_loss(assignment)
-        h3 = time.perf_counter()
-        if detail: marks[2].record()
         if world > 1:
+            if overlap:
+                nms_stream.wait_event(reduced_after)                      # the loss wrote stats on the other stream
             stats = stats.clone() if backend == "nccl" else stats.cpu()   # (host tensor only in the gloo rehearsal)
-            if overlap:      # the collective waits for the loss on the side stream: the next decode does not wait for the other ranks
-                reduced_after = torch.cuda.Event()
-                reduced_after.record()
-                set_stream(nms_stream)
-                nms_stream.wait_event(reduced_after)
             dist.all_reduce(stats, op=dist.ReduceOp.SUM)          # [lbox, lobj, lcls, n_pos] over RCCL
         if overlap:
             set_stream(main_stream)
-        h4 = time.perf_counter()
+        h3 = time.perf_counter()
         if record:
-            for s, d in zip(stages, (h1 - h0, h4 - h2, h2 - h1, 0.0)):
+            for s, d in zip(stages, (h1 - h0, h2 - h1, h3 - h2, 0.0)):
                 host_s[s] += d
-        return dict(marks=marks, z=z, assignment=assignment, rows=rows, host_meta=host_meta, copied=copied, loss=loss, grads=grads, stats=stats)
+        return dict(marks=marks, z=z, rows=rows, host_meta=host_meta, copied=copied, loss=loss, grads=grads, stats=stats)
 
     def finish(job):
         """Host half of a step: wait for that step's copy only, then build the per-image detection views."""
