@@ -230,6 +230,119 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
     }
 }
 
+// ------------------------------------------------------------------------------------------ 1' prefilter, streaming
+// Multi-label candidates are (row, class) pairs that are judged one by one (obj > conf and obj*cls > conf,
+// general.py:656,691,698): no per-row reduction is needed, so when most rows are candidates anyway (validation
+// thresholds) the whole tensor is streamed once with coalesced 16-byte loads -- at several times the rate of fetching
+// candidate rows one by one -- and every element with a class channel is tested where it lands.  The key set is the
+// same as k_nms_prefilter<true>'s; only the emission order differs, and the sort that follows does not depend on it.
+#define STREAM_UNROLL 2
+#define STREAM_TILES 16      // consecutive tiles per workgroup: candidates are gathered in LDS across them, one atomic per flush
+
+struct stream_seg {
+    const float* src;      // (bs, elems): one level's raw map, or the whole decoded tensor
+    uint32_t elems;        // floats per image
+    uint32_t row_first;    // first row (anchor) of this segment inside an image
+    uint32_t blocks;
+};
+
+struct stream_params {
+    stream_seg seg[DH_MAX_LEVELS];
+    int nseg;
+    dh_fastdiv no;
+};
+
+template <bool RAW>
+__global__ void __launch_bounds__(256) k_nms_prefilter_stream(const stream_params P, const float* __restrict__ obj_plane,
+                                                              int A, int nc, float conf,
+                                                              const unsigned char* __restrict__ class_keep, int cap,
+                                                              u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
+{
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int l = 0;
+    uint32_t blk = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < DH_MAX_LEVELS - 1; ++k)
+        if (l == k && k + 1 < P.nseg && blk >= P.seg[k].blocks) { blk -= P.seg[k].blocks; l = k + 1; }
+    const stream_seg& G = P.seg[l];
+    const uint32_t no = P.no.d;
+    const uint32_t nvec = G.elems >> 2;
+    const float* __restrict__ src = G.src + (size_t)b * G.elems;
+    const float* __restrict__ plane = obj_plane ? obj_plane + (size_t)b * A + G.row_first : nullptr;
+    u64* __restrict__ out = keys + (size_t)b * cap_pad;
+    __shared__ u64 stage[4][STAGE_KEYS];
+    int pending = 0;
+#pragma unroll 1
+    for (int tile = 0; tile < STREAM_TILES; ++tile) {
+    const uint32_t v0 = (blk * STREAM_TILES + tile) * (256 * STREAM_UNROLL) + threadIdx.x;
+    if (v0 - threadIdx.x >= nvec) break;
+    dh_f4 x[STREAM_UNROLL];
+    float o0[STREAM_UNROLL], o1[STREAM_UNROLL];
+    uint32_t row[STREAM_UNROLL], c0[STREAM_UNROLL];
+    // every load of the tile is issued before the first use: the data vectors and the objectness of the (at most two)
+    // rows each vector belongs to
+#pragma unroll
+    for (int u = 0; u < STREAM_UNROLL; ++u) {
+        const uint32_t v = v0 + u * 256;
+        o0[u] = 0.0f; o1[u] = 0.0f; row[u] = 0; c0[u] = 0;
+        if (v < nvec) {
+            x[u] = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(src) + v);
+            const uint32_t e = v * 4;
+            row[u] = dh_div(e, P.no);
+            c0[u] = e - row[u] * no;
+            const bool two = c0[u] + 3 >= no;
+            if (RAW || !plane) {
+                o0[u] = src[(size_t)row[u] * no + 4];
+                if (two) o1[u] = src[(size_t)(row[u] + 1) * no + 4];
+            } else {
+                o0[u] = plane[row[u]];
+                if (two) o1[u] = plane[row[u] + 1];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < STREAM_UNROLL; ++u) {
+        const uint32_t v = v0 + u * 256;
+        const bool live = v < nvec;
+        const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+        const float oa = RAW ? dh_sigmoid(o0[u]) : o0[u], ob = RAW ? dh_sigmoid(o1[u]) : o1[u];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t ch = c0[u] + k, r = row[u];
+            float o = oa;
+            if (ch >= no) { ch -= no; r += 1; o = ob; }
+            const int c = (int)ch - 5;
+            const float val = RAW ? dh_sigmoid(xs[k]) : xs[k];                                  // yolo.py:62
+            const float sc = val * o;                                                           // general.py:691
+            bool pass = live && c >= 0 && (o > conf) && (sc > conf);                            // general.py:656,698
+            if (class_keep != nullptr && pass) pass = class_keep[c] != 0;                       // general.py:705-706
+            const u64 pm = __ballot(pass);
+            if (pm) {
+                if (pass) stage[wave][pending + __popcll(pm & lanemask_lt())] =
+                    ((u64)score_key(sc) << 32) | (uint32_t)((G.row_first + r) * nc + c);
+                pending += __popcll(pm);
+            }
+        }
+        if (pending > STAGE_KEYS - 4 * 64) {            // one atomic per > 256 keys; the next vector adds at most 256
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&counts[b], pending);
+            base = __shfl(base, 0, 64);
+            for (int i = lane; i < pending; i += 64)
+                if (base + i < cap) out[base + i] = stage[wave][i];
+            pending = 0;
+        }
+    }
+    }
+    if (pending) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&counts[b], pending);
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < pending; i += 64)
+            if (base + i < cap) out[base + i] = stage[wave][i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ 2/4 sort
 __device__ __forceinline__ void cmpswap(u64& a, u64& b, bool ascending)
 {
@@ -940,12 +1053,46 @@ int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A
 
     int* cursor = (int*)(ws + L.off_cursor);
     if (hipMemsetAsync(ws, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;   // every counter's initial state is 0
+    // Multi-label at a validation-style threshold straight from the raw maps: most rows are candidates and there is no
+    // compact objectness plane to scan, so the maps are streamed once instead of being visited row by row (measured
+    // 163 against 278 us at bs 64).  With a decoded tensor and its plane the row-by-row kernel stays ahead.
+    bool streamed = false;
+    if (raw && multi_label && conf_thres < 0.05 && nc + 5 >= 7) {
+        stream_params SP;
+        SP.no = dh_make_fastdiv((uint32_t)(nc + 5));
+        bool ok = true;
+        uint32_t sgx = 0;
+        if (raw) {
+            SP.nseg = S.nl;
+            for (int l = 0; l < S.nl; ++l) {
+                SP.seg[l].src = S.lvl[l].src; SP.seg[l].elems = S.lvl[l].elems; SP.seg[l].row_first = S.lvl[l].row_first;
+            }
+        } else {
+            SP.nseg = 1;
+            SP.seg[0].src = S.pred; SP.seg[0].row_first = 0;
+            ok = (unsigned long long)A * (nc + 5) < (1ull << 31);
+            SP.seg[0].elems = ok ? (uint32_t)A * (uint32_t)(nc + 5) : 0;
+        }
+        for (int l = 0; ok && l < SP.nseg; ++l) {
+            ok = (SP.seg[l].elems % 4 == 0) && dh_aligned16(SP.seg[l].src);
+            SP.seg[l].blocks = (SP.seg[l].elems / 4 + 256 * STREAM_UNROLL * STREAM_TILES - 1) / (256 * STREAM_UNROLL * STREAM_TILES);
+            sgx += SP.seg[l].blocks;
+        }
+        if (ok) {
+            if (raw) hipLaunchKernelGGL(k_nms_prefilter_stream<true>, dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane, A, nc, conf,
+                                        class_keep, cap, keys, L.cap_pad, counts);
+            else hipLaunchKernelGGL(k_nms_prefilter_stream<false>, dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane, A, nc, conf,
+                                    class_keep, cap, keys, L.cap_pad, counts);
+            streamed = true;
+        }
+    }
     int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks
     const int gx_cap = 8192 / bs > 1 ? 8192 / bs : 1;
     if (gx > gx_cap) gx = gx_cap;
 #define DH_PREFILTER(M, N, R) hipLaunchKernelGGL((k_nms_prefilter<M, N, R>), dim3(gx, bs), dim3(256), 0, st, S, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
 #define DH_PREFILTER_N(M, R) do { if (nc <= 64) DH_PREFILTER(M, 1, R); else if (nc <= 128) DH_PREFILTER(M, 2, R); else DH_PREFILTER(M, 0, R); } while (0)
-    if (multi_label) { if (raw) DH_PREFILTER_N(true, true); else DH_PREFILTER_N(true, false); }
+    if (streamed) { /* candidates already emitted */ }
+    else if (multi_label) { if (raw) DH_PREFILTER_N(true, true); else DH_PREFILTER_N(true, false); }
     else { if (raw) DH_PREFILTER_N(false, true); else DH_PREFILTER_N(false, false); }
 #undef DH_PREFILTER_N
 #undef DH_PREFILTER
