@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""One validation batch end to end on the device (object_detection/yolov5/val.py:194-232): loss on the raw maps, NMS at
+the validation thresholds, detection/label matching and the confusion matrix.  Wall clock, device-synchronised.
+
+  python tools/time_val_pipeline.py [--batch 64] [--iters 10]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    from object_detection_amd.general import detect_nms, non_max_suppression, xywh2xyxy
+    from object_detection_amd.metrics import ConfusionMatrix
+    from object_detection_amd.val import process_batches
+    from object_detection_amd.yolo import detect_decode
+    from object_detection_amd.yolo_loss import ComputeLoss
+    bs, nc = args.batch, 80
+    anchors = bench.grid_anchors(dev)
+    crit = ComputeLoss(bench._Model(anchors, nc))
+    levels, targets = bench.synth_batch(bs, 640, nc, 10 * bs, 1000, dev)
+    bench.plant_objects(levels, targets, crit)
+    strides = torch.tensor([8., 16., 32.])
+    iouv = torch.linspace(0.5, 0.95, 10, device=dev)
+    scale = torch.tensor([640., 640., 640., 640.], device=dev)
+    # labels per image in pixels, [cls, x1, y1, x2, y2] (val.py:222-225), prepared once: they come from the data loader
+    img = targets[:, 0].long().cpu()
+    tbox = xywh2xyxy(targets[:, 2:6] * scale)
+    labels = [torch.cat((targets[img == i, 1:2], tbox[img == i]), 1) for i in range(bs)]
+    cm = ConfusionMatrix(nc=nc)
+
+    def step(fused):
+        with torch.no_grad():
+            if fused:
+                out = detect_nms(levels, anchors, strides, 0.001, 0.6, multi_label=True)
+            else:
+                out = non_max_suppression(detect_decode(levels, anchors, strides), 0.001, 0.6, multi_label=True)
+            loss, items = crit(levels, targets)                      # val.py:198 (compute_loss on the raw maps)
+            correct = process_batches(out, labels, iouv)             # val.py:230, whole batch
+            cm.process_batches(out, labels)                          # val.py:232
+        return out, correct, items
+
+    for fused in (False, True):
+        step(fused)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.iters):
+            out, correct, items = step(fused)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.iters * 1e3
+        n_correct = int(sum(int(c[:, 0].sum()) for c in correct))
+        print(f"{'fused detect_nms' if fused else 'decode + NMS    '} + loss + matching + confusion matrix: {ms:7.3f} ms per batch of {bs} "
+              f"({bs / ms * 1e3:9.0f} img/s); {sum(o.shape[0] for o in out)} detections, {n_correct} correct @0.5", flush=True)
+
+
+if __name__ == "__main__":
+    main()
