@@ -321,7 +321,10 @@ def main():
     roofline = {"kernel": "k_yolo_decode", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc.get("k_yolo_decode_bytes_per_launch"),
-                "algorithmic_bytes_per_launch": decode_bytes, "avg_launch_ms": round(stage_ms["decode"], 4)}
+                "algorithmic_bytes_per_launch": decode_bytes, "avg_launch_ms": round(stage_ms["decode"], 4),
+                # the same kernel's average in the committed rocprofv3 --kernel-trace --stats run of this command
+                # (the event bracket above adds the two marker packets and the dispatch latency to it)
+                "rocprof_avg_launch_ms": round(pmc.get("per_launch", {}).get("k_yolo_decode", {}).get("avg_us", 0.0) / 1e3, 4) or None}
 
     if rank == 0:
         line = {
