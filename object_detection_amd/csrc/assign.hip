@@ -26,20 +26,24 @@ struct bt_params {
     long cap;   // rows reserved per level = 5*na*nt
 };
 
-__device__ __forceinline__ int block_rank(bool flag, int& total, int* s_w)
+// Position of this thread's flag among the set flags of the workgroup (row-major) and their total.  Consecutive
+// calls alternate between two count buffers (`phase` toggles), so one barrier per call is enough: nobody can still
+// be reading buffer k when it is written again two calls later, because the call in between has its own barrier.
+__device__ __forceinline__ int block_rank(bool flag, int& total, int (*s_w)[BT_THREADS / 64], int& phase)
 {
     const unsigned long long m = __ballot(flag);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) s_w[wave] = __popcll(m);
+    int* cnt = s_w[phase];
+    phase ^= 1;
+    if (lane == 0) cnt[wave] = __popcll(m);
     __syncthreads();
     int before = 0, all = 0;
 #pragma unroll
     for (int w = 0; w < BT_THREADS / 64; ++w) {
-        const int c = s_w[w];
+        const int c = cnt[w];
         if (w < wave) before += c;
         all += c;
     }
-    __syncthreads();
     total = all;
     return before + __popcll(m & ((1ull << lane) - 1ull));
 }
@@ -59,7 +63,8 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
                                                               long long* __restrict__ tcls, int* __restrict__ counts,
                                                               uint4* __restrict__ fill, size_t fill_vecs)
 {
-    __shared__ int s_w[BT_THREADS / 64];
+    __shared__ int s_w[2][BT_THREADS / 64];
+    int phase = 0;
     if ((int)blockIdx.x >= P.nl) {      // side duty of the same launch: set a caller's region to all ones (16 B per store)
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         const size_t step = (size_t)(gridDim.x - P.nl) * BT_THREADS;
@@ -86,7 +91,7 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
             ok = worst < P.anchor_t;
         }
         int tot;
-        const int rank = block_rank(ok, tot, s_w);
+        const int rank = block_rank(ok, tot, s_w, phase);
         if (ok) list[n1 + rank] = q;
         n1 += tot;
     }
@@ -119,7 +124,7 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
                 else { const float iy = fny - gy; take = (remainder_one(iy) < 0.5f) && (iy > 1.0f); }
             }
             int tot;
-            const int rank = block_rank(take, tot, s_w);
+            const int rank = block_rank(take, tot, s_w, phase);
             if (take) {
                 const size_t pos = (size_t)n2 + rank;
                 const float ox = off == 1 ? 0.5f : (off == 3 ? -0.5f : 0.0f);
