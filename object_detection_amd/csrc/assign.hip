@@ -16,6 +16,7 @@
 namespace {
 
 #define BT_THREADS 1024
+#define BT_CHUNKS 2       // rows per thread that the single-sweep expansion keeps in registers
 
 struct bt_params {
     int ny[DH_MAX_LEVELS];
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
     }
     __syncthreads();   // list[] written by this workgroup is read back below
 
-    // stage 2: one pass per neighbour offset keeps the offset-major order (loss.py:197-203)
+    // stage 2: expansion to the neighbour cells, in offset-major order (loss.py:197-203)
     long long* __restrict__ ob = idx + (size_t)l * 4 * P.cap;
     long long* __restrict__ oa = ob + P.cap;
     long long* __restrict__ oj = oa + P.cap;
@@ -106,46 +107,110 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
     float* __restrict__ oanch = anch + (size_t)l * P.cap * 2;
     long long* __restrict__ ocls = tcls + (size_t)l * P.cap;
     int n2 = 0;
-    for (int off = 0; off < 5; ++off) {
-        for (int k0 = 0; k0 < n1; k0 += BT_THREADS) {
-            const int k = k0 + threadIdx.x;
-            bool take = false;
-            int a = 0, t = 0;
-            float gx = 0.f, gy = 0.f;
+    // Which of the five offsets a row takes (bit o of the result) -- loss.py:197-203
+    auto offsets_taken = [&](float gx, float gy) -> unsigned {
+        const float ix = fnx - gx, iy = fny - gy;
+        unsigned bits = 1u;
+        if ((remainder_one(gx) < 0.5f) && (gx > 1.0f)) bits |= 2u;
+        if ((remainder_one(gy) < 0.5f) && (gy > 1.0f)) bits |= 4u;
+        if ((remainder_one(ix) < 0.5f) && (ix > 1.0f)) bits |= 8u;
+        if ((remainder_one(iy) < 0.5f) && (iy > 1.0f)) bits |= 16u;
+        return bits;
+    };
+    auto emit = [&](size_t pos, int off, int a, int t, float gx, float gy) {
+        const float ox = off == 1 ? 0.5f : (off == 3 ? -0.5f : 0.0f);
+        const float oy = off == 2 ? 0.5f : (off == 4 ? -0.5f : 0.0f);
+        long long gi = (long long)(gx - ox), gj = (long long)(gy - oy);           // .long(): truncation
+        gi = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);                            // loss.py:217
+        gj = gj < 0 ? 0 : (gj > ny - 1 ? ny - 1 : gj);
+        const float* __restrict__ tr = targets + (size_t)t * 6;
+        ob[pos] = (long long)tr[0];
+        oa[pos] = a;
+        oj[pos] = gj;
+        oi[pos] = gi;
+        obox[4 * pos + 0] = gx - (float)gi;
+        obox[4 * pos + 1] = gy - (float)gj;
+        obox[4 * pos + 2] = tr[4] * fnx;
+        obox[4 * pos + 3] = tr[5] * fny;
+        oanch[2 * pos + 0] = anc[2 * a];
+        oanch[2 * pos + 1] = anc[2 * a + 1];
+        ocls[pos] = (long long)tr[1];
+    };
+    if (n1 <= BT_CHUNKS * BT_THREADS) {
+        // The usual size: every thread owns at most BT_CHUNKS rows.  All offsets are counted in one sweep
+        // (per offset, chunk and wave), one wave turns the counts into offset-major start positions, and a second
+        // sweep writes -- three barriers instead of one per (offset, chunk).
+        __shared__ int s_cnt[5 * BT_CHUNKS * (BT_THREADS / 64) + 1];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        unsigned bits[BT_CHUNKS];
+        int ra[BT_CHUNKS], rt[BT_CHUNKS];
+        float rgx[BT_CHUNKS], rgy[BT_CHUNKS];
+#pragma unroll
+        for (int ch = 0; ch < BT_CHUNKS; ++ch) {
+            const int k = ch * BT_THREADS + threadIdx.x;
+            bits[ch] = 0; ra[ch] = 0; rt[ch] = 0; rgx[ch] = 0.f; rgy[ch] = 0.f;
             if (k < n1) {
                 const int q = list[k];
-                a = q / P.nt; t = q - a * P.nt;
-                gx = targets[(size_t)t * 6 + 2] * fnx;
-                gy = targets[(size_t)t * 6 + 3] * fny;
-                if (off == 0) take = true;
-                else if (off == 1) take = (remainder_one(gx) < 0.5f) && (gx > 1.0f);
-                else if (off == 2) take = (remainder_one(gy) < 0.5f) && (gy > 1.0f);
-                else if (off == 3) { const float ix = fnx - gx; take = (remainder_one(ix) < 0.5f) && (ix > 1.0f); }
-                else { const float iy = fny - gy; take = (remainder_one(iy) < 0.5f) && (iy > 1.0f); }
+                ra[ch] = q / P.nt; rt[ch] = q - ra[ch] * P.nt;
+                rgx[ch] = targets[(size_t)rt[ch] * 6 + 2] * fnx;
+                rgy[ch] = targets[(size_t)rt[ch] * 6 + 3] * fny;
+                bits[ch] = offsets_taken(rgx[ch], rgy[ch]);
             }
-            int tot;
-            const int rank = block_rank(take, tot, s_w, phase);
-            if (take) {
-                const size_t pos = (size_t)n2 + rank;
-                const float ox = off == 1 ? 0.5f : (off == 3 ? -0.5f : 0.0f);
-                const float oy = off == 2 ? 0.5f : (off == 4 ? -0.5f : 0.0f);
-                long long gi = (long long)(gx - ox), gj = (long long)(gy - oy);           // .long(): truncation
-                gi = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);                            // loss.py:217
-                gj = gj < 0 ? 0 : (gj > ny - 1 ? ny - 1 : gj);
-                const float* __restrict__ tr = targets + (size_t)t * 6;
-                ob[pos] = (long long)tr[0];
-                oa[pos] = a;
-                oj[pos] = gj;
-                oi[pos] = gi;
-                obox[4 * pos + 0] = gx - (float)gi;
-                obox[4 * pos + 1] = gy - (float)gj;
-                obox[4 * pos + 2] = tr[4] * fnx;
-                obox[4 * pos + 3] = tr[5] * fny;
-                oanch[2 * pos + 0] = anc[2 * a];
-                oanch[2 * pos + 1] = anc[2 * a + 1];
-                ocls[pos] = (long long)tr[1];
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                const unsigned long long m = __ballot((bits[ch] >> o) & 1u);
+                if (lane == 0) s_cnt[(o * BT_CHUNKS + ch) * (BT_THREADS / 64) + wave] = __popcll(m);
             }
-            n2 += tot;
+        }
+        __syncthreads();
+        if (wave == 0) {      // exclusive prefix sum over the 5 * BT_CHUNKS * 16 counts, in output order
+            constexpr int N = 5 * BT_CHUNKS * (BT_THREADS / 64);
+            constexpr int PER = (N + 63) / 64;
+            int v[PER], sum = 0;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { const int i = lane * PER + j; v[j] = i < N ? s_cnt[i] : 0; sum += v[j]; }
+            int incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+            int run = incl - sum;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { const int i = lane * PER + j; if (i < N) s_cnt[i] = run; run += v[j]; }
+            if (lane == 63) s_cnt[N] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < BT_CHUNKS; ++ch) {
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                const bool take = (bits[ch] >> o) & 1u;
+                const unsigned long long m = __ballot(take);
+                if (take) {
+                    const size_t pos = (size_t)s_cnt[(o * BT_CHUNKS + ch) * (BT_THREADS / 64) + wave] +
+                                       __popcll(m & ((1ull << lane) - 1ull));
+                    emit(pos, o, ra[ch], rt[ch], rgx[ch], rgy[ch]);
+                }
+            }
+        }
+        n2 = s_cnt[5 * BT_CHUNKS * (BT_THREADS / 64)];
+    } else {
+        for (int off = 0; off < 5; ++off) {      // any size: one pass per neighbour offset keeps the offset-major order
+            for (int k0 = 0; k0 < n1; k0 += BT_THREADS) {
+                const int k = k0 + threadIdx.x;
+                bool take = false;
+                int a = 0, t = 0;
+                float gx = 0.f, gy = 0.f;
+                if (k < n1) {
+                    const int q = list[k];
+                    a = q / P.nt; t = q - a * P.nt;
+                    gx = targets[(size_t)t * 6 + 2] * fnx;
+                    gy = targets[(size_t)t * 6 + 3] * fny;
+                    take = (offsets_taken(gx, gy) >> off) & 1u;
+                }
+                int tot;
+                const int rank = block_rank(take, tot, s_w, phase);
+                if (take) emit((size_t)n2 + rank, off, a, t, gx, gy);
+                n2 += tot;
+            }
         }
     }
     if (threadIdx.x == 0) counts[l] = n2;
