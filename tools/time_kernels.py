@@ -32,7 +32,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--only", default="decode,loss,nms,centernet")
+    ap.add_argument("--only", default="decode,loss,nms,centernet,iou")
     args = ap.parse_args()
     only = set(args.only.split(","))
     dev = torch.device("cuda", 0)
@@ -82,6 +82,22 @@ def main():
         del zc
         us = timed(lambda: non_max_suppression(z, 0.001, 0.6, multi_label=True, max_det=300), args.iters)
         print(f"nms 0.001/0.6 ml  {us:9.1f} us")
+    if "iou" in only:      # element-wise IoU family on N pairs: 16 B + 16 B read, 4 B written (+16 B gradient)
+        from object_detection_amd.metrics import bbox_iou
+        for n in (1 << 20, 1 << 24):
+            g = torch.Generator(device=dev).manual_seed(5)
+            b1 = (torch.rand((4, n), generator=g, device=dev) + 0.1).requires_grad_(True)
+            b2 = torch.rand((n, 4), generator=g, device=dev) + 0.1
+            for kw, name in ((dict(), "IoU"), (dict(CIoU=True), "CIoU")):
+                us = timed(lambda: bbox_iou(b1.detach(), b2, x1y1x2y2=False, **kw), args.iters)
+                print(f"bbox_iou {name:4s} fwd  n={n:9d} {us:9.1f} us  {36.0 * n / us / 1e3:8.1f} GB/s (36 B/pair)")
+
+                def fb():
+                    v = bbox_iou(b1, b2, x1y1x2y2=False, **kw)
+                    torch.autograd.grad(v.sum(), b1)
+                us2 = timed(fb, args.iters)
+                print(f"bbox_iou {name:4s} f+b  n={n:9d} {us2:9.1f} us  (incl. the sum and the autograd engine)")
+            del b1, b2
     if "centernet" in only:
         B, W, H = bs, 160, 160
         g = torch.Generator(device=dev).manual_seed(3)
