@@ -52,7 +52,7 @@ def decode_bbox(pred_cls, pred_size, pred_offset, confidence, device=None):
     with L.device_guard(heat.device):
         L.check(lib.dh_centernet_decode(L.ptr(heat), L.ptr(size), L.ptr(off), B, C, W, H, float(confidence), L.ptr(det),
                                         L.ptr(counts), L.ptr(ws), ws_bytes, L.stream()), "dh_centernet_decode")
-    out = _Decoded(det[i, :k] if k else [] for i, k in enumerate(counts.tolist()))
+    out = _Decoded(d.narrow(0, 0, k) if k else [] for d, k in zip(det.unbind(0), counts.tolist()))
     out.buffer, out.counts, out.num_classes, out.version = det, counts, int(C), det._version
     return out
 

@@ -98,6 +98,57 @@ def test_centernet_decode_full_size_vs_oracle():
     np.testing.assert_array_equal(C.pool_nms(T(heat).cuda()).cpu().numpy(), oc.pool_nms(T(heat)).numpy())
 
 
+@pytest.mark.parametrize("shape", [(1, 1), (5, 3), (7, 62), (9, 63), (3, 125), (33, 4), (17, 8), (6, 256), (70, 100),
+                                   (3, 1024), (2, 1028), (10, 200), (1, 64), (64, 1)])
+def test_centernet_peak_filter_shapes_vs_oracle(shape):
+    """Map shapes on both sides of every kernel choice: H a multiple of four or not, rows longer than a wave or a
+    workgroup, row counts that leave partial row groups, ties between neighbours."""
+    from object_detection_amd import centernet as C
+    W, H = shape
+    rs = np.random.RandomState(W * 1031 + H)
+    B, Cn = 2, 5
+    heat = rs.normal(-1.0, 1.0, (B, Cn, W, H)).astype(np.float32)
+    heat[rs.rand(B, Cn, W, H) < 0.2] = 0.25                                   # equal neighbours: all of a plateau stay
+    heat[0, 0] = 0.0                                                          # a class map of zeros
+    np.testing.assert_array_equal(C.pool_nms(T(heat).cuda()).cpu().numpy(), oc.pool_nms(T(heat)).numpy())
+    size = np.abs(rs.normal(6, 3, (B, 2, W, H))).astype(np.float32)
+    off = rs.uniform(0, 1, (B, 2, W, H)).astype(np.float32)
+    conf = 0.1
+    lim_lo, lim_hi = np.arctanh(conf - 1e-3), np.arctanh(conf + 1e-3)
+    heat[(heat > lim_lo) & (heat < lim_hi)] = -2.0
+    want = oc.decode_bbox(T(heat), T(size), T(off), conf)
+    got = C.decode_bbox(T(heat).cuda(), T(size).cuda(), T(off).cuda(), conf)
+    for d, w in zip(got, want):
+        assert len(d) == len(w)
+        if len(w):
+            np.testing.assert_array_equal(d[:, 5].cpu().numpy(), w[:, 5].numpy())
+            np.testing.assert_array_equal(d[:, :4].cpu().numpy(), w[:, :4].numpy())
+            np.testing.assert_allclose(d[:, 4].cpu().numpy(), w[:, 4].numpy(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(12, 16), (9, 7)])
+def test_centernet_best_class_tanh_ties(shape):
+    """Different heat values whose tanh rounds to the same float: the first such class wins, as torch.max over the
+    tanh'ed maps picks it (dataset.py:183-186), although a later class holds the larger heat value."""
+    from object_detection_amd import centernet as C
+    W, H = shape
+    heat = np.full((1, 8, W, H), -3.0, dtype=np.float32)
+    heat[0, 3, 2, 5] = 10.0          # tanh -> 1.0f
+    heat[0, 5, 2, 5] = 11.0          # larger, also 1.0f
+    heat[0, 6, 4, 1] = 12.0
+    heat[0, 1, 4, 1] = 30.0          # the larger value first: no tie to resolve
+    heat[0, 2, 7, 6] = 0.5
+    heat[0, 4, 7, 6] = 0.7           # an ordinary maximum at a later class
+    size = np.full((1, 2, W, H), 2.0, dtype=np.float32)
+    off = np.zeros((1, 2, W, H), dtype=np.float32)
+    want = oc.decode_bbox(T(heat), T(size), T(off), 0.3)[0]
+    got = C.decode_bbox(T(heat).cuda(), T(size).cuda(), T(off).cuda(), 0.3)[0]
+    assert want[:, 5].tolist() == [3.0, 1.0, 4.0]
+    np.testing.assert_array_equal(got[:, 5].cpu().numpy(), want[:, 5].numpy())
+    np.testing.assert_array_equal(got[:, :4].cpu().numpy(), want[:, :4].numpy())
+    np.testing.assert_allclose(got[:, 4].cpu().numpy(), want[:, 4].numpy(), rtol=1e-5)
+
+
 def test_centernet_targets(golden):
     from object_detection_amd.centernet import centernet_targets
     g = golden("centernet")

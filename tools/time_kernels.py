@@ -99,7 +99,18 @@ def main():
                 print(f"bbox_iou {name:4s} f+b  n={n:9d} {us2:9.1f} us  (incl. the sum and the autograd engine)")
             del b1, b2
     if "centernet" in only:
+        from object_detection_amd import centernet as CN
         B, W, H = bs, 160, 160
+        g = torch.Generator(device=dev).manual_seed(4)
+        heat = torch.randn((B, 80, W, H), generator=g, device=dev) - 1.5
+        size = torch.rand((B, 2, W, H), generator=g, device=dev) * 10
+        off = torch.rand((B, 2, W, H), generator=g, device=dev)
+        hb = heat.numel() * 4.0
+        us = timed(lambda: CN.pool_nms(heat), args.iters)
+        print(f"centernet pool_nms         {us:9.1f} us  {2 * hb / us / 1e3:8.1f} GB/s (read + write the class maps)")
+        us = timed(lambda: CN.decode_bbox(heat, size, off, 0.9), args.iters)
+        print(f"centernet decode_bbox      {us:9.1f} us  {hb / us / 1e3:8.1f} GB/s (one read of the class maps; incl. the count copy)")
+        del heat, size, off
         g = torch.Generator(device=dev).manual_seed(3)
         mask = (torch.rand((B, W, H), generator=g, device=dev) < 0.005).float()
         ls = torch.rand((B, 2, W, H), generator=g, device=dev) * 20 * mask[:, None]
