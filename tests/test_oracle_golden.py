@@ -310,3 +310,24 @@ def test_tta_descale_and_clip_oracle_vs_reference(golden):
     ys = oy.clip_augmented([torch.from_numpy(base), torch.from_numpy(base[:, :900]), torch.from_numpy(base[:, :400])], 3)
     np.testing.assert_array_equal([y.shape[1] for y in ys], g["clip_shapes"])
     np.testing.assert_array_equal(np.stack([ys[0][0, -1].numpy(), ys[-1][0, 0].numpy()]), g["clip_first_last"])
+
+
+AP_CASES = ("empty", "one", "small", "single_iou", "all_fp", "all_tp", "absent", "coco_like", "one_class_long")
+AP_OUT = ("tp", "fp", "p", "r", "f1", "ap", "classes")
+
+
+@pytest.mark.parametrize("tag", AP_CASES)
+def test_ap_per_class_oracle_vs_reference(golden, tag):
+    """metrics.py:21-114: every output of the reference's ap_per_class, bit for bit (float64)."""
+    import warnings
+    from oracle import ap as oa
+    g = golden("ap")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = oa.ap_per_class(g[f"{tag}_in_tp"], g[f"{tag}_in_conf"], g[f"{tag}_in_pred_cls"], g[f"{tag}_in_target_cls"])
+    for nm, v in zip(AP_OUT, got):
+        want = g[f"{tag}_{nm}"]
+        assert v.dtype == want.dtype and v.shape == want.shape, nm
+        np.testing.assert_array_equal(v, want, err_msg=nm)
+    if tag == "small":
+        np.testing.assert_array_equal(oa.fitness(g["fitness_in"]), g["fitness_out"])

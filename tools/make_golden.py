@@ -565,11 +565,63 @@ def gen_tta():
     save("tta", **out)
 
 
+def ap_case(rs, n, nc, n_lab, niou=10, p_hit=0.6, absent=()):
+    """Evaluation statistics as val.py collects them: tp (n, niou) bool (a hit at a higher IoU threshold implies the
+    lower ones, at most one hit per label), conf (n,) float32 all different, pred_cls (n,) float32, target_cls (m,) float64."""
+    target_cls = rs.randint(0, nc, n_lab).astype(np.float64)
+    target_cls = target_cls[~np.isin(target_cls, absent)]
+    pred_cls = rs.randint(0, nc + 1, n).astype(np.float32)               # class nc never has labels
+    conf = rs.permutation(np.linspace(0.002, 0.998, max(n, 1)).astype(np.float32))[:n]
+    assert len(np.unique(conf)) == n
+    tp = np.zeros((n, niou), dtype=bool)
+    for c in range(nc):
+        idx = np.flatnonzero(pred_cls == c)
+        n_l = int((target_cls == c).sum())
+        hits = idx[rs.rand(len(idx)) < p_hit][:n_l]
+        depth = rs.randint(1, niou + 1, len(hits))
+        for h, d in zip(hits, depth):
+            tp[h, :d] = True
+    return tp, conf, pred_cls, target_cls
+
+
+def gen_ap(y_metrics):
+    """metrics.py:21-114 from the untouched reference (plot=False)."""
+    import warnings
+    from oracle import ap as oa
+    rs = np.random.RandomState(77)
+    cases = {"empty": ap_case(rs, 0, 3, 10), "one": ap_case(rs, 1, 1, 1, p_hit=1.0), "small": ap_case(rs, 40, 3, 25),
+             "single_iou": ap_case(rs, 300, 4, 80, niou=1), "all_fp": ap_case(rs, 200, 5, 60, p_hit=0.0),
+             "all_tp": ap_case(rs, 50, 2, 400, p_hit=1.0), "absent": ap_case(rs, 500, 6, 200, absent=(2, 4)),
+             "coco_like": ap_case(rs, 20000, 80, 6000), "one_class_long": ap_case(rs, 30000, 1, 9000, p_hit=0.5)}
+    out = {}
+    names = ("tp", "fp", "p", "r", "f1", "ap", "classes")
+    for tag, (tp, conf, pcls, tcls) in cases.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                               # np.trapz deprecation, 0/0 in all-fp columns
+            want = y_metrics.ap_per_class(tp, conf, pcls, tcls, plot=False, names={})     # names=() (the default) raises at :74
+            mine = oa.ap_per_class(tp, conf, pcls, tcls)
+        for nm, w, m in zip(names, want, mine):
+            assert w.dtype == m.dtype and np.array_equal(w, m, equal_nan=True), (tag, nm)
+            out[f"{tag}_{nm}"] = w
+        out[f"{tag}_in_tp"], out[f"{tag}_in_conf"], out[f"{tag}_in_pred_cls"], out[f"{tag}_in_target_cls"] = tp, conf, pcls, tcls
+        print(f"  ap {tag}: n {len(conf)}, classes {len(want[6])}, mAP@0.5 {want[5][:, 0].mean() if len(want[6]) else 0:.4f}")
+    x = rs.rand(6, 7)
+    assert np.array_equal(y_metrics.fitness(x), oa.fitness(x))
+    out["fitness_in"], out["fitness_out"] = x, y_metrics.fitness(x)
+    save("ap", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(1)
     y_metrics, y_general, y_loss, a_loss, c_loss, c_data = load_reference()
+    only = set(sys.argv[1:])
+    if only:                      # e.g. `make_golden.py ap`: regenerate the named fixtures only
+        gens = {"ap": lambda: gen_ap(y_metrics), "evalmatch": lambda: gen_evalmatch(y_metrics), "tta": gen_tta}
+        for k in only:
+            gens[k]()
+        return
     gen_bbox_iou(y_metrics, a_loss)
     gen_pairwise(y_metrics)
     gen_box_utils(y_general)
@@ -579,6 +631,7 @@ def main():
     gen_centernet(a_loss, c_loss, c_data)
     gen_evalmatch(y_metrics)
     gen_tta()
+    gen_ap(y_metrics)
 
 
 if __name__ == "__main__":
