@@ -233,6 +233,23 @@ int dh_confusion_update(const float* det, const float* labels, const int* det_fi
                         int64_t n_det, int64_t n_labels, int nc, double conf, double iou_thres, unsigned long long* matrix,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* Per-class average precision and precision / recall / F1 at the best mean-F1 confidence, from the statistics an
+ * evaluation run collects (object_detection/yolov5/utils/metrics.py:21-86 ap_per_class with plot=False, :89-114
+ * compute_ap).  All pointers are device memory; float64 arithmetic in the reference's operation order.
+ * dh_ap_classes: target_cls (m doubles, integer class ids in [0, class_cap)) -> unique (ascending class ids) and nt
+ *   (labels per class), both class_cap ints; meta[0] = number of classes with labels, meta[1] != 0 when an id was not an
+ *   integer in range; bins is class_cap ints of scratch.  The caller reads meta back to size the outputs.
+ * dh_ap_per_class: tp (n, niou) bytes 0/1, conf (n) and pred_cls (n) floats, unique / nt / n_unique from above ->
+ *   ap (n_unique, niou), p_curve and r_curve (n_unique, 1000), out5 (5, n_unique) rows tp, fp, p, r, f1, best_index (the
+ *   column of the curves that out5 was taken at).  Detections of one class with equal confidence keep their input order.
+ * workspace: device, 256-byte aligned, dh_ap_per_class_workspace(n, niou) bytes (needs a GPU to size: the sort's
+ *   scratch depends on the device). */
+int dh_ap_classes(const double* target_cls, int64_t m, int class_cap, int* unique, int* nt, int* meta, int* bins, void* stream);
+size_t dh_ap_per_class_workspace(int64_t n, int niou);
+int dh_ap_per_class(const unsigned char* tp, const float* conf, const float* pred_cls, int64_t n, int niou, const int* unique,
+                    const int* nt, int n_unique, int class_cap, double eps, double* ap, double* p_curve, double* r_curve,
+                    double* out5, int* best_index, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

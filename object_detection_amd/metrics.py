@@ -1,4 +1,7 @@
-"""Drop-ins for object_detection/yolov5/utils/metrics.py:201-296 (bbox_iou, box_iou, wh_iou, bbox_ioa)."""
+"""Drop-ins for object_detection/yolov5/utils/metrics.py: bbox_iou, box_iou, wh_iou, bbox_ioa (:201-296),
+ConfusionMatrix (:116-171), ap_per_class / fitness (:15-86)."""
+import warnings
+
 import numpy as np
 import torch
 
@@ -151,3 +154,72 @@ class ConfusionMatrix:
         tp = m.diagonal()
         fp = m.sum(1) - tp
         return tp[:-1], fp[:-1]
+
+
+AP_CLASS_CAP = 1 << 16      # class ids are integers in [0, AP_CLASS_CAP)
+
+
+def fitness(x):
+    """Weighted combination of [P, R, mAP@0.5, mAP@0.5:0.95] (metrics.py:15-18); host arithmetic on a (k, >=4) array."""
+    w = [0.0, 0.0, 0.1, 0.9]
+    return (x[:, :4] * w).sum(1)
+
+
+def _to_device(a, dtype, device, name):
+    if isinstance(a, torch.Tensor):
+        if not a.is_cuda:
+            a = a.to(device)
+        return a.to(dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a)).to(device=device, dtype=dtype).contiguous()
+
+
+def ap_per_class(tp, conf, pred_cls, target_cls, plot=False, save_dir='.', names=(), eps=1e-16):
+    """Average precision per class and IoU threshold, and tp / fp / precision / recall / F1 per class at the confidence
+    of the best mean F1 (metrics.py:21-86) -> (tp, fp, p, r, f1, ap, unique_classes) as numpy arrays (float64, classes int32).
+
+    tp (n, n_iou) bool, conf (n,), pred_cls (n,), target_cls (m,): numpy arrays as val.py collects them, or device tensors
+    (no per-image host copies are needed then).  One sort and one workgroup per (class, IoU threshold) replace the
+    reference's per-class Python loop; two small host reads (the class list, the results).  The curve plots of the
+    reference (plot=True) are not drawn.  Detections of one class with equal confidence keep their input order, where
+    the reference's unstable argsort may order them either way.
+    """
+    if plot:
+        warnings.warn("ap_per_class: the precision/recall curve plots are not drawn")
+    dev = next((a.device for a in (tp, conf, pred_cls, target_cls) if isinstance(a, torch.Tensor) and a.is_cuda),
+               torch.device("cuda", torch.cuda.current_device()))
+    if not isinstance(conf, torch.Tensor):
+        c64 = np.asarray(conf)
+        if c64.dtype != np.float32 and not np.array_equal(c64.astype(np.float32), c64):
+            raise ValueError("ap_per_class: confidences must be float32 values (as val.py collects them)")
+    tp_d = _to_device(tp, torch.uint8, dev, "tp")
+    if tp_d.dim() == 1:
+        tp_d = tp_d[:, None]
+    conf_d = _to_device(conf, torch.float32, dev, "conf")
+    cls_d = _to_device(pred_cls, torch.float32, dev, "pred_cls")
+    tcls_d = _to_device(target_cls, torch.float64, dev, "target_cls").reshape(-1)
+    n, niou = tp_d.shape
+    if conf_d.shape != (n,) or cls_d.shape != (n,):
+        raise RuntimeError(f"ap_per_class: tp {tuple(tp_d.shape)}, conf {tuple(conf_d.shape)}, pred_cls {tuple(cls_d.shape)} disagree")
+    lib = L.lib()
+    m = tcls_d.numel()
+    ints = torch.empty((3, AP_CLASS_CAP), dtype=torch.int32, device=dev)          # unique, nt, histogram scratch
+    meta = torch.empty(2, dtype=torch.int32, device=dev)
+    with L.device_guard(dev):
+        L.check(lib.dh_ap_classes(L.ptr(tcls_d), m, AP_CLASS_CAP, L.ptr(ints[0]), L.ptr(ints[1]), L.ptr(meta), L.ptr(ints[2]),
+                                  L.stream()), "dh_ap_classes")
+        nu, bad = meta.tolist()
+        if bad:
+            raise ValueError(f"ap_per_class: target classes must be integers in [0, {AP_CLASS_CAP})")
+        ap = torch.empty((nu, niou), dtype=torch.float64, device=dev)
+        out5 = torch.empty((5, nu), dtype=torch.float64, device=dev)
+        unique = ints[0, :nu]
+        if nu:
+            curves = torch.empty((2, nu, 1000), dtype=torch.float64, device=dev)
+            best = torch.empty(1, dtype=torch.int32, device=dev)
+            ws_bytes = lib.dh_ap_per_class_workspace(n, niou)
+            ws = L.workspace(ws_bytes, dev)
+            L.check(lib.dh_ap_per_class(L.ptr(tp_d), L.ptr(conf_d), L.ptr(cls_d), n, niou, L.ptr(unique), L.ptr(ints[1]), nu,
+                                        AP_CLASS_CAP, float(eps), L.ptr(ap), L.ptr(curves[0]), L.ptr(curves[1]), L.ptr(out5),
+                                        L.ptr(best), L.ptr(ws), ws_bytes, L.stream()), "dh_ap_per_class")
+    o = out5.cpu().numpy()
+    return o[0], o[1], o[2], o[3], o[4], ap.cpu().numpy(), unique.cpu().numpy().astype("int32")
