@@ -250,6 +250,14 @@ int dh_ap_per_class(const unsigned char* tp, const float* conf, const float* pre
                     const int* nt, int n_unique, int class_cap, double eps, double* ap, double* p_curve, double* r_curve,
                     double* out5, int* best_index, void* workspace, size_t workspace_bytes, void* stream);
 
+/* AutoAnchor's fit of n anchors k (n,2) to N label sizes wh (N,2), all device fp32
+ * (object_detection/yolov5/utils/autoanchor.py:86-90 metric, :92-94 anchor_fitness, :35-41 the check_anchors metric).
+ * x (N,n) and best (N) are optional outputs (NULL to skip); sums (3 device doubles) receives the sum over labels of
+ * best*(best>thr), the number of labels with best > thr, and the number of (label, anchor) pairs with x > thr.
+ * thr is the inverted threshold (autoanchor.py:84), compared in fp32.  n <= 64. */
+int dh_anchor_metric(const float* wh, int64_t N, const float* k, int n, double thr, float* x, float* best, double* sums,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -331,3 +331,17 @@ def test_ap_per_class_oracle_vs_reference(golden, tag):
         np.testing.assert_array_equal(v, want, err_msg=nm)
     if tag == "small":
         np.testing.assert_array_equal(oa.fitness(g["fitness_in"]), g["fitness_out"])
+
+
+@pytest.mark.parametrize("tag", ["default", "poor", "tight", "one"])
+def test_autoanchor_metric_oracle_vs_reference(golden, tag):
+    """autoanchor.py:35-41, 86-94: the closures' outputs, bit for bit."""
+    from oracle import autoanchor as oaa
+    g = golden("autoanchor")
+    k, wh, thr = torch.from_numpy(g[f"{tag}_k"]), torch.from_numpy(g[f"{tag}_wh"]), float(g[f"{tag}_thr"])
+    x, best = oaa.metric(k, wh)
+    np.testing.assert_array_equal(x.numpy(), g[f"{tag}_x"])
+    np.testing.assert_array_equal(best.numpy(), g[f"{tag}_best"])
+    bpr, aat = oaa.check_metric(k, wh, thr)
+    fit = oaa.anchor_fitness(g[f"{tag}_k"], wh, 1 / thr)
+    np.testing.assert_array_equal(np.array([bpr.item(), aat.item(), fit.item()], dtype=np.float32), g[f"{tag}_stats"])

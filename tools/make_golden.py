@@ -611,6 +611,52 @@ def gen_ap(y_metrics):
     save("ap", **out)
 
 
+def reference_autoanchor_closures(wh, thr):
+    """utils/autoanchor.py keeps its metrics as closures inside check_anchors / kmean_anchors; the nested function
+    definitions alone are compiled from the reference's file at run time, with the variables they capture (wh, thr)
+    bound in their namespace."""
+    import ast
+    path = os.path.join(REF, "yolov5", "utils", "autoanchor.py")
+    tree = ast.parse(open(path).read(), path)
+    outer = {n.name: n for n in tree.body if isinstance(n, ast.FunctionDef)}
+    check = [n for n in outer["check_anchors"].body if isinstance(n, ast.FunctionDef) and n.name == "metric"]
+    kmean = [n for n in outer["kmean_anchors"].body if isinstance(n, ast.FunctionDef) and n.name in ("metric", "anchor_fitness")]
+    ns_check = {"torch": torch, "wh": wh, "thr": thr}
+    exec(compile(ast.Module(body=check, type_ignores=[]), path, "exec"), ns_check)
+    ns_kmean = {"torch": torch, "wh": wh, "thr": 1 / thr}                   # autoanchor.py:84
+    exec(compile(ast.Module(body=kmean, type_ignores=[]), path, "exec"), ns_kmean)
+    return ns_check["metric"], ns_kmean["metric"], ns_kmean["anchor_fitness"]
+
+
+def gen_autoanchor():
+    """autoanchor.py:35-41, 86-94 on label sizes like a 640 px dataset's, against the default anchors and poor ones."""
+    from oracle import autoanchor as oaa
+    rs = np.random.RandomState(11)
+    out = {}
+    default = np.array([[10, 13], [16, 30], [33, 23], [30, 61], [62, 45], [59, 119], [116, 90], [156, 198], [373, 326]], dtype=np.float32)
+    cases = {"default": (default, 5000, 4.0), "poor": (default[:3] * 0.2, 3000, 4.0), "tight": (default, 2000, 2.0),
+             "one": (default[4:5], 1, 4.0)}
+    for tag, (k, n, thr) in cases.items():
+        wh = torch.from_numpy(np.exp(rs.uniform(np.log(2), np.log(600), (n, 2))).astype(np.float32))
+        if n > 10:
+            wh[0] = torch.tensor([10.0, 13.0])                               # a label equal to an anchor: ratio exactly 1
+            wh[1] = torch.tensor([40.0, 52.0])                               # exactly on the threshold 1/4 of the first anchor
+        check_metric, metric, fitness = reference_autoanchor_closures(wh, thr)
+        kt = torch.from_numpy(k)
+        bpr, aat = check_metric(kt)
+        x, best = metric(kt, wh)
+        fit = fitness(k)
+        mb, ma = oaa.check_metric(kt, wh, thr)
+        mx, mbest = oaa.metric(kt, wh)
+        assert torch.equal(bpr, mb) and torch.equal(aat, ma) and torch.equal(x, mx) and torch.equal(best, mbest)
+        assert torch.equal(fit, oaa.anchor_fitness(k, wh, 1 / thr))
+        out[f"{tag}_k"], out[f"{tag}_wh"], out[f"{tag}_thr"] = k, wh.numpy(), np.array(thr)
+        out[f"{tag}_x"], out[f"{tag}_best"] = x.numpy(), best.numpy()
+        out[f"{tag}_stats"] = np.array([bpr.item(), aat.item(), fit.item()], dtype=np.float32)
+        print(f"  autoanchor {tag}: bpr {bpr:.4f}, aat {aat:.3f}, fitness {fit:.4f}")
+    save("autoanchor", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -618,7 +664,8 @@ def main():
     y_metrics, y_general, y_loss, a_loss, c_loss, c_data = load_reference()
     only = set(sys.argv[1:])
     if only:                      # e.g. `make_golden.py ap`: regenerate the named fixtures only
-        gens = {"ap": lambda: gen_ap(y_metrics), "evalmatch": lambda: gen_evalmatch(y_metrics), "tta": gen_tta}
+        gens = {"ap": lambda: gen_ap(y_metrics), "evalmatch": lambda: gen_evalmatch(y_metrics), "tta": gen_tta,
+                "autoanchor": gen_autoanchor}
         for k in only:
             gens[k]()
         return
@@ -632,6 +679,7 @@ def main():
     gen_evalmatch(y_metrics)
     gen_tta()
     gen_ap(y_metrics)
+    gen_autoanchor()
 
 
 if __name__ == "__main__":
