@@ -71,6 +71,12 @@ int dh_centernet_box_loss_bwd(const float* pred_xy, int64_t pred_xy_bstride, con
 int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
                    const float* anchor_px, const float* strides, float* out, float* obj_plane, float* obj_logit_plane,
                    void* stream);
+/* The same for a half-precision head (model.half() of object_detection/yolov5/val.py:115,129): the level maps hold fp16
+ * elements, which are widened on load; the arithmetic and every output stay fp32, so the result equals
+ * dh_yolo_decode on the maps converted to fp32, without that conversion pass (170 instead of 340 B read per anchor). */
+int dh_yolo_decode_f16(const void* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                       const float* anchor_px, const float* strides, float* out, float* obj_plane, float* obj_logit_plane,
+                       void* stream);
 
 /* Batched non_max_suppression (object_detection/yolov5/utils/general.py:647-738) over
  * pred (bs, A, 5+nc) = [x,y,w,h,obj,cls...].  Output rows are [x1,y1,x2,y2,conf,cls] in the
@@ -104,6 +110,12 @@ int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny, const int*
                        int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
                        int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* The same on fp16 level maps (see dh_yolo_decode_f16): equal to dh_yolo_decode_nms on the maps converted to fp32. */
+int dh_yolo_decode_nms_f16(const void* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                           const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
+                           int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+                           int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* torchvision.ops.nms(boxes[n,4] xyxy, scores[n], iou_threshold) as called at
  * object_detection/yolov5/utils/general.py:722 and object_detection/detectors/centernet/dataset.py:263:

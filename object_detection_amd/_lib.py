@@ -32,12 +32,17 @@ SIGNATURES = {
                                           c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
     "dh_yolo_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dh_yolo_decode_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "dh_nms_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dh_nms_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p, c_int, c_int,
                                c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_decode_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
                                    c_double, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_yolo_decode_nms_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
+                                       c_double, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_int, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_nms_plain_workspace": (c_size_t, [c_i64]),
     "dh_nms_plain": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_box_convert": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p]),
@@ -151,6 +156,14 @@ def dev_f32(t, name="tensor"):
     if not t.is_cuda:
         raise RuntimeError(f"{name} is on {t.device}: object_detection_amd only runs on ROCm devices (no CPU fallback)")
     return t if t.dtype == torch.float32 else t.float()
+
+
+def head_maps(levels, name="x"):
+    """The raw head maps as the kernels take them: (contiguous tensors, is_half).  A head that runs in half precision
+    (every map fp16) is read as it is; anything else goes through dev_f32."""
+    if levels and all(isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float16 for x in levels):
+        return [x.contiguous() for x in levels], True
+    return [dev_f32(x, f"{name}[{i}]").contiguous() for i, x in enumerate(levels)], False
 
 
 def workspace(nbytes, device):

@@ -34,7 +34,25 @@ struct decode_params {
 // decomposed once per vector, not once per element) and free of memory instructions (the level
 // record is read into scalar registers up front), so the loads already in flight are never waited for.
 #define DH_PIN_SGPR(v) asm volatile("" : "+s"(v))
-template <int VEC, int DH_DEC_UNROLL, int NT>
+typedef _Float16 dh_h4 __attribute__((ext_vector_type(4)));
+
+// four consecutive map elements as fp32; fp16 maps (T = _Float16) are widened on load, and everything after the load is
+// the fp32 arithmetic: a half-precision head decodes to exactly what its maps converted with .float() decode to
+template <bool NT_LOAD>
+__device__ __forceinline__ dh_f4 load4(const float* p)
+{
+    if (NT_LOAD) return __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(p));
+    return *reinterpret_cast<const dh_f4*>(p);
+}
+template <bool NT_LOAD>
+__device__ __forceinline__ dh_f4 load4(const _Float16* p)
+{
+    const dh_h4 h = NT_LOAD ? __builtin_nontemporal_load(reinterpret_cast<const dh_h4*>(p)) : *reinterpret_cast<const dh_h4*>(p);
+    const dh_f4 f = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return f;
+}
+
+template <int VEC, int DH_DEC_UNROLL, int NT, typename T = float>
 __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, float* __restrict__ out)
 {
     const int b = blockIdx.y;
@@ -47,7 +65,7 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
     const decode_level& L = P.lvl[l];
     const uint32_t nvec = L.elems / VEC;
     const uint32_t no = P.no.d;
-    const float* __restrict__ src = L.src + (size_t)b * L.elems;
+    const T* __restrict__ src = reinterpret_cast<const T*>(L.src) + (size_t)b * L.elems;
     float* __restrict__ dst = out + (size_t)b * P.per_image + L.first;
     const uint32_t v0 = blk * (256 * DH_DEC_UNROLL) + threadIdx.x;
     if (VEC == 4) {
@@ -63,10 +81,7 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
 #pragma unroll
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
             const uint32_t v = v0 + u * 256;
-            if (v < nvec) {
-                if (NT & 1) x[u] = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(src + (size_t)v * 4));
-                else x[u] = *reinterpret_cast<const dh_f4*>(src + (size_t)v * 4);
-            }
+            if (v < nvec) x[u] = load4<(NT & 1) != 0>(src + (size_t)v * 4);
         }
 #pragma unroll
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
@@ -119,7 +134,7 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
         for (int u = 0; u < DH_DEC_UNROLL; ++u) {
             const uint32_t v = v0 + u * 256;
             if (v >= nvec) continue;
-            const float xv = src[v];
+            const float xv = (float)src[v];
             float y = dh_sigmoid(xv);
             const uint32_t row = dh_div(v, P.no);
             const uint32_t c = v - row * no;
@@ -135,9 +150,10 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
 
 }  // namespace
 
-extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
-                              int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
-                              float* obj_logit_plane, void* stream)
+namespace {
+
+int decode_run(const float* const* level_ptrs, bool half, const int* ny, const int* nx, int nl, int bs, int na, int no,
+               const float* anchor_px, const float* strides, float* out, float* obj_plane, float* obj_logit_plane, void* stream)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 5 || bs < 0 || bs > 65535) return DH_ERR_ARG;
     if (!level_ptrs || !ny || !nx || !anchor_px || !strides || (bs > 0 && !out)) return DH_ERR_ARG;
@@ -146,8 +162,11 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
     P.nl = nl;
     P.no = dh_make_fastdiv((uint32_t)no);
     bool vec4 = false;
-    if (!dh_make_levels(level_ptrs, ny, nx, nl, na, no, anchor_px, strides, P.lvl, &P.per_image, &P.rows_per_image, &vec4))
+    if (!dh_make_levels(level_ptrs, ny, nx, nl, na, no, anchor_px, strides, P.lvl, &P.per_image, &P.rows_per_image, &vec4,
+                        half ? 7 : 15))
         return DH_ERR_ARG;
+    for (int l = 0; half && l < nl; ++l)
+        if (reinterpret_cast<uintptr_t>(level_ptrs[l]) & 1u) return DH_ERR_ALIGN;
     vec4 = vec4 && dh_aligned16(out) && no >= 7;
     if (obj_logit_plane && !obj_plane) return DH_ERR_ARG;   // the logit copy rides on the objectness-plane path
     P.obj_plane = obj_plane;
@@ -171,14 +190,34 @@ extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, con
         gx += P.blocks[l];
     }
     hipStream_t st = (hipStream_t)stream;
-#define DH_DEC(U, N) hipLaunchKernelGGL((k_yolo_decode<4, U, N>), dim3(gx, bs), dim3(256), 0, st, P, out)
+#define DH_DEC(U, N) do { if (half) hipLaunchKernelGGL((k_yolo_decode<4, U, N, _Float16>), dim3(gx, bs), dim3(256), 0, st, P, out); \
+                          else hipLaunchKernelGGL((k_yolo_decode<4, U, N>), dim3(gx, bs), dim3(256), 0, st, P, out); } while (0)
 #define DH_DEC_NT(U) do { if (nt == 0) DH_DEC(U, 0); else if (nt == 1) DH_DEC(U, 1); else if (nt == 2) DH_DEC(U, 2); else DH_DEC(U, 3); } while (0)
     if (vec4) {
         if (unroll == 1) DH_DEC_NT(1); else if (unroll == 2) DH_DEC_NT(2); else if (unroll == 8) DH_DEC_NT(8); else DH_DEC_NT(4);
+    } else if (half) {
+        hipLaunchKernelGGL((k_yolo_decode<1, 4, 0, _Float16>), dim3(gx, bs), dim3(256), 0, st, P, out);
     } else {
         hipLaunchKernelGGL((k_yolo_decode<1, 4, 0>), dim3(gx, bs), dim3(256), 0, st, P, out);
     }
 #undef DH_DEC_NT
 #undef DH_DEC
     return dh_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
+                              int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
+                              float* obj_logit_plane, void* stream)
+{
+    return decode_run(level_ptrs, false, ny, nx, nl, bs, na, no, anchor_px, strides, out, obj_plane, obj_logit_plane, stream);
+}
+
+extern "C" int dh_yolo_decode_f16(const void* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
+                                  int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
+                                  float* obj_logit_plane, void* stream)
+{
+    return decode_run(reinterpret_cast<const float* const*>(level_ptrs), true, ny, nx, nl, bs, na, no, anchor_px, strides, out,
+                      obj_plane, obj_logit_plane, stream);
 }

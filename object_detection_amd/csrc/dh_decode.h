@@ -5,7 +5,8 @@
 #include "../../include/dethead.h"
 
 struct decode_level {
-    const float* src;     // (bs, na, ny, nx, no) contiguous
+    const float* src;     // (bs, na, ny, nx, no) contiguous; fp16 maps travel under the same pointer type and are
+                          // cast back by the kernels that were told so
     uint32_t first;       // first output element of this level inside one image's span
     uint32_t row_first;   // first output row (anchor) of this level inside one image
     uint32_t elems;       // na*ny*nx*no
@@ -30,10 +31,11 @@ __device__ __forceinline__ float decode_box(const decode_level& L, uint32_t row,
 }
 
 // Fills the level records from the host-side description; returns false on an unsupported shape.
-// vec4_ok (optional) reports whether every level span is a multiple of 4 floats and 16-byte aligned.
+// vec4_ok (optional) reports whether every level span is a multiple of 4 elements and aligned for a 4-element load
+// (align_mask 15 for fp32 maps, 7 for fp16 maps).
 static inline bool dh_make_levels(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int na, int no,
                                   const float* anchor_px, const float* strides, decode_level* lvl, uint32_t* per_image,
-                                  uint32_t* rows_per_image, bool* vec4_ok)
+                                  uint32_t* rows_per_image, bool* vec4_ok, uintptr_t align_mask = 15)
 {
     uint64_t first = 0;
     uint32_t row_first = 0;
@@ -52,7 +54,7 @@ static inline bool dh_make_levels(const float* const* level_ptrs, const int* ny,
         L.nx = dh_make_fastdiv((uint32_t)nx[l]);
         L.stride = strides[l];
         for (int k = 0; k < 2 * na; ++k) L.anchor_px[k] = anchor_px[l * 2 * na + k];
-        vec4 = vec4 && (elems % 4 == 0) && dh_aligned16(level_ptrs[l]);
+        vec4 = vec4 && (elems % 4 == 0) && (reinterpret_cast<uintptr_t>(level_ptrs[l]) & align_mask) == 0;
         first += elems;
     }
     *per_image = (uint32_t)first;

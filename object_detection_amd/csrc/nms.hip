@@ -63,22 +63,44 @@ struct nms_source {
     int nl, no;
 };
 
+// The raw maps hold fp32 or fp16 elements (T = float or _Float16; decode_level::src is then a pointer in disguise).
+// fp16 values are widened to fp32 on load and everything after that is the fp32 arithmetic, so a half-precision head
+// gives exactly the detections of its maps converted with .float() -- without that conversion pass.
+typedef _Float16 dh_h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const _Float16* p) { return (float)*p; }
+__device__ __forceinline__ float ldf_nt(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float ldf_nt(const _Float16* p) { return (float)__builtin_nontemporal_load(p); }
+__device__ __forceinline__ dh_f4 ld4_nt(const float* p, uint32_t v)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(p) + v);
+}
+__device__ __forceinline__ dh_f4 ld4_nt(const _Float16* p, uint32_t v)
+{
+    const dh_h4 h = __builtin_nontemporal_load(reinterpret_cast<const dh_h4*>(p) + v);
+    const dh_f4 f = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+    return f;
+}
+
+template <typename T>
 struct raw_row {
-    const float* p;   // first element of the row inside its map
+    const T* p;       // first element of the row inside its map
     int l;            // level
     uint32_t local;   // row index inside the level (anchor-major, then gy, gx)
 };
 
-__device__ __forceinline__ raw_row raw_row_of(const nms_source& S, int b, int row)
+template <typename T>
+__device__ __forceinline__ raw_row<T> raw_row_of(const nms_source& S, int b, int row)
 {
     int l = 0;
 #pragma unroll
     for (int k = 1; k < DH_MAX_LEVELS; ++k)
         if (k < S.nl && (uint32_t)row >= S.lvl[k].row_first) l = k;
-    raw_row r;
+    raw_row<T> r;
     r.l = l;
     r.local = (uint32_t)row - S.lvl[l].row_first;
-    r.p = S.lvl[l].src + (size_t)b * S.lvl[l].elems + (size_t)r.local * S.no;
+    r.p = reinterpret_cast<const T*>(S.lvl[l].src) + (size_t)b * S.lvl[l].elems + (size_t)r.local * S.no;
     return r;
 }
 
@@ -103,7 +125,7 @@ __device__ __forceinline__ row_best wave_argmax_first(float v, int c)
 // NCH > 0: the class scores of the rows in flight are fetched up front as NCH chunks of 64 classes
 // (nc <= 64*NCH), which keeps 4*NCH independent loads in flight per wave; NCH = 0 handles any nc
 // chunk by chunk.
-template <bool MULTI, int NCH, bool RAW>
+template <bool MULTI, int NCH, bool RAW, typename T = float>
 __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const float* __restrict__ obj_plane,
                                                        int A, int nc, float conf,
                                                        const unsigned char* __restrict__ class_keep, int cap,
@@ -122,7 +144,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
         float obj = 0.0f;
         if (row < A) {
             // the strided column is touched once: non-temporal loads fetch single 64-byte sectors (2.2x faster cold)
-            if (RAW) obj = dh_sigmoid(__builtin_nontemporal_load(raw_row_of(S, b, row).p + 4));
+            if (RAW) obj = dh_sigmoid(ldf_nt(raw_row_of<T>(S, b, row).p + 4));
             else obj = obj_plane ? obj_plane[(size_t)b * A + row] : __builtin_nontemporal_load(img + (size_t)row * no + 4);
         }
         const bool cand = (row < A) && (obj > conf);                       // general.py:656,675
@@ -147,12 +169,12 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
             }
             float bv[4];
             int bc[4];
-            const float* rp[4];      // first class score of each row in flight (wave-uniform)
+            const T* rp[4];          // first class score of each row in flight (wave-uniform)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 bv[k] = -INFINITY;
                 bc[k] = 0x7fffffff;
-                rp[k] = (RAW ? raw_row_of(S, b, row0 + r[k]).p : img + (size_t)(row0 + r[k]) * no) + 5;
+                rp[k] = (RAW ? raw_row_of<T>(S, b, row0 + r[k]).p : reinterpret_cast<const T*>(img + (size_t)(row0 + r[k]) * no)) + 5;
             }
             float pre[4][NCH > 0 ? NCH : 1];
             if (NCH > 0) {
@@ -160,7 +182,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int h = 0; h < NCH; ++h)
-                        pre[k][h] = (h * 64 + lane < nc) ? rp[k][h * 64 + lane] : 0.0f;
+                        pre[k][h] = (h * 64 + lane < nc) ? ldf(rp[k] + h * 64 + lane) : 0.0f;
             }
             const int nch = NCH > 0 ? NCH : (nc + 63) / 64;
 #pragma unroll
@@ -170,7 +192,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (NCH > 0) v[k] = pre[k][NCH > 0 ? h : 0];
-                    else v[k] = (c < nc) ? rp[k][c] : 0.0f;
+                    else v[k] = (c < nc) ? ldf(rp[k] + c) : 0.0f;
                     if (RAW) v[k] = dh_sigmoid(v[k]);          // yolo.py:62
                 }
                 const bool keepc = (c < nc) && (class_keep == nullptr || class_keep[c] != 0);   // general.py:705-706
@@ -240,8 +262,8 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
 #define STREAM_TILES 16      // consecutive tiles per workgroup: candidates are gathered in LDS across them, one atomic per flush
 
 struct stream_seg {
-    const float* src;      // (bs, elems): one level's raw map, or the whole decoded tensor
-    uint32_t elems;        // floats per image
+    const float* src;      // (bs, elems): one level's raw map (fp32 or fp16 elements), or the whole decoded tensor
+    uint32_t elems;        // elements per image
     uint32_t row_first;    // first row (anchor) of this segment inside an image
     uint32_t blocks;
 };
@@ -252,7 +274,7 @@ struct stream_params {
     dh_fastdiv no;
 };
 
-template <bool RAW>
+template <bool RAW, typename T = float>
 __global__ void __launch_bounds__(256) k_nms_prefilter_stream(const stream_params P, const float* __restrict__ obj_plane,
                                                               int A, int nc, float conf,
                                                               const unsigned char* __restrict__ class_keep, int cap,
@@ -268,7 +290,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_stream(const stream_param
     const stream_seg& G = P.seg[l];
     const uint32_t no = P.no.d;
     const uint32_t nvec = G.elems >> 2;
-    const float* __restrict__ src = G.src + (size_t)b * G.elems;
+    const T* __restrict__ src = reinterpret_cast<const T*>(G.src) + (size_t)b * G.elems;
     const float* __restrict__ plane = obj_plane ? obj_plane + (size_t)b * A + G.row_first : nullptr;
     u64* __restrict__ out = keys + (size_t)b * cap_pad;
     __shared__ u64 stage[4][STAGE_KEYS];
@@ -287,14 +309,14 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_stream(const stream_param
         const uint32_t v = v0 + u * 256;
         o0[u] = 0.0f; o1[u] = 0.0f; row[u] = 0; c0[u] = 0;
         if (v < nvec) {
-            x[u] = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(src) + v);
+            x[u] = ld4_nt(src, v);
             const uint32_t e = v * 4;
             row[u] = dh_div(e, P.no);
             c0[u] = e - row[u] * no;
             const bool two = c0[u] + 3 >= no;
             if (RAW || !plane) {
-                o0[u] = src[(size_t)row[u] * no + 4];
-                if (two) o1[u] = src[(size_t)(row[u] + 1) * no + 4];
+                o0[u] = ldf(src + (size_t)row[u] * no + 4);
+                if (two) o1[u] = ldf(src + (size_t)(row[u] + 1) * no + 4);
             } else {
                 o0[u] = plane[row[u]];
                 if (two) o1[u] = plane[row[u] + 1];
@@ -593,7 +615,7 @@ struct img_range {   // per image: coordinate range of the boxes that reach NMS 
     int bad, pad;
 };
 
-template <bool RAW>
+template <bool RAW, typename T = float>
 __global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, dh_fastdiv ncd,
                                                     const u64* __restrict__ keys, int cap_pad,
                                                     const int* __restrict__ m_arr,
@@ -613,12 +635,12 @@ __global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, d
         const uint32_t cls = ord - anchor * ncd.d;
         float x, y, w, h;
         if (RAW) {
-            const raw_row rr = raw_row_of(S, b, (int)anchor);
+            const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
             const decode_level& L = S.lvl[rr.l];
-            x = decode_box(L, rr.local, 0, dh_sigmoid(rr.p[0]));
-            y = decode_box(L, rr.local, 1, dh_sigmoid(rr.p[1]));
-            w = decode_box(L, rr.local, 2, dh_sigmoid(rr.p[2]));
-            h = decode_box(L, rr.local, 3, dh_sigmoid(rr.p[3]));
+            x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p + 0)));
+            y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + 1)));
+            w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2)));
+            h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3)));
         } else {
             const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
             x = p[0]; y = p[1]; w = p[2]; h = p[3];
@@ -1023,7 +1045,7 @@ extern "C" size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms)
 
 namespace {
 
-int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
+int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
             int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
             int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
             size_t workspace_bytes, void* stream)
@@ -1074,13 +1096,15 @@ int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A
             SP.seg[0].elems = ok ? (uint32_t)A * (uint32_t)(nc + 5) : 0;
         }
         for (int l = 0; ok && l < SP.nseg; ++l) {
-            ok = (SP.seg[l].elems % 4 == 0) && dh_aligned16(SP.seg[l].src);
+            ok = (SP.seg[l].elems % 4 == 0) && (half ? (reinterpret_cast<uintptr_t>(SP.seg[l].src) & 7u) == 0 : dh_aligned16(SP.seg[l].src));
             SP.seg[l].blocks = (SP.seg[l].elems / 4 + 256 * STREAM_UNROLL * STREAM_TILES - 1) / (256 * STREAM_UNROLL * STREAM_TILES);
             sgx += SP.seg[l].blocks;
         }
         if (ok) {
-            if (raw) hipLaunchKernelGGL(k_nms_prefilter_stream<true>, dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane, A, nc, conf,
-                                        class_keep, cap, keys, L.cap_pad, counts);
+            if (raw && half) hipLaunchKernelGGL((k_nms_prefilter_stream<true, _Float16>), dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane,
+                                                A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
+            else if (raw) hipLaunchKernelGGL(k_nms_prefilter_stream<true>, dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane, A, nc, conf,
+                                             class_keep, cap, keys, L.cap_pad, counts);
             else hipLaunchKernelGGL(k_nms_prefilter_stream<false>, dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane, A, nc, conf,
                                     class_keep, cap, keys, L.cap_pad, counts);
             streamed = true;
@@ -1089,11 +1113,12 @@ int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A
     int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks
     const int gx_cap = 8192 / bs > 1 ? 8192 / bs : 1;
     if (gx > gx_cap) gx = gx_cap;
-#define DH_PREFILTER(M, N, R) hipLaunchKernelGGL((k_nms_prefilter<M, N, R>), dim3(gx, bs), dim3(256), 0, st, S, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
-#define DH_PREFILTER_N(M, R) do { if (nc <= 64) DH_PREFILTER(M, 1, R); else if (nc <= 128) DH_PREFILTER(M, 2, R); else DH_PREFILTER(M, 0, R); } while (0)
+#define DH_PREFILTER(M, N, R, T) hipLaunchKernelGGL((k_nms_prefilter<M, N, R, T>), dim3(gx, bs), dim3(256), 0, st, S, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
+#define DH_PREFILTER_N(M, R, T) do { if (nc <= 64) DH_PREFILTER(M, 1, R, T); else if (nc <= 128) DH_PREFILTER(M, 2, R, T); else DH_PREFILTER(M, 0, R, T); } while (0)
     if (streamed) { /* candidates already emitted */ }
-    else if (multi_label) { if (raw) DH_PREFILTER_N(true, true); else DH_PREFILTER_N(true, false); }
-    else { if (raw) DH_PREFILTER_N(false, true); else DH_PREFILTER_N(false, false); }
+    else if (raw && half) { if (multi_label) DH_PREFILTER_N(true, true, _Float16); else DH_PREFILTER_N(false, true, _Float16); }
+    else if (multi_label) { if (raw) DH_PREFILTER_N(true, true, float); else DH_PREFILTER_N(true, false, float); }
+    else { if (raw) DH_PREFILTER_N(false, true, float); else DH_PREFILTER_N(false, false, float); }
 #undef DH_PREFILTER_N
 #undef DH_PREFILTER
     // score order: either the best k_target rows per image (select + sort in LDS) or all of them
@@ -1110,7 +1135,10 @@ int nms_run(const nms_source& S, bool raw, const float* obj_plane, int bs, int A
     }
     const int m_rows = k_target > 0 ? SORT_LDS_KEYS : L.m_cap;         // upper bound of m_arr[]
     const dim3 ggrid((m_rows + 255) / 256, bs);
-    if (raw)
+    if (raw && half)
+        hipLaunchKernelGGL((k_nms_gather<true, _Float16>), ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), ranked,
+                           ranked_pad, m_arr, det, keys2, L.m_pad, L.m_cap, range);
+    else if (raw)
         hipLaunchKernelGGL(k_nms_gather<true>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), ranked, ranked_pad,
                            m_arr, det, keys2, L.m_pad, L.m_cap, range);
     else
@@ -1143,15 +1171,17 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
     S.pred = pred;
     S.nl = 0;
     S.no = nc + 5;
-    return nms_run(S, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
+    return nms_run(S, false, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
                    max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
 
-extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
-                                  const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
-                                  int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
-                                  double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
-                                  int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+namespace {
+
+int decode_nms_run(const void* const* level_ptrs, bool half, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                   const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
+                   int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap, int k_select,
+                   float* out, int* out_span, int* cand_count, int* needs_full, void* workspace, size_t workspace_bytes,
+                   void* stream)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 6) return DH_ERR_ARG;
     if (!level_ptrs || !ny || !nx || !anchor_px || !strides) return DH_ERR_ARG;
@@ -1160,9 +1190,37 @@ extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny,
     S.nl = nl;
     S.no = no;
     uint32_t per_image = 0, rows = 0;
-    if (!dh_make_levels(level_ptrs, ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image, &rows, nullptr)) return DH_ERR_ARG;
-    return nms_run(S, true, nullptr, bs, (int)rows, no - 5, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det,
+    if (!dh_make_levels(reinterpret_cast<const float* const*>(level_ptrs), ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image,
+                        &rows, nullptr))
+        return DH_ERR_ARG;
+    for (int l = 0; half && l < nl; ++l)
+        if (reinterpret_cast<uintptr_t>(level_ptrs[l]) & 1u) return DH_ERR_ALIGN;
+    return nms_run(S, true, half, nullptr, bs, (int)rows, no - 5, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det,
                    max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
+}
+
+}  // namespace
+
+extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                                  const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
+                                  int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
+                                  double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                  int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return decode_nms_run(reinterpret_cast<const void* const*>(level_ptrs), false, ny, nx, nl, bs, na, no, anchor_px, strides,
+                          conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out,
+                          out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_decode_nms_f16(const void* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                                      const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
+                                      int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
+                                      double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                      int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return decode_nms_run(level_ptrs, true, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label, agnostic,
+                          class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace,
+                          workspace_bytes, stream);
 }
 
 extern "C" size_t dh_group_nms_workspace(int n_img, int max_rows, int nc)

@@ -159,7 +159,7 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     nms_launch(detect_decode(levels, anchors, stride), ...), without writing or reading the decoded tensor."""
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
-    xs = [L.dev_f32(x, f"x[{i}]").contiguous() for i, x in enumerate(levels)]
+    xs, half = L.head_maps(levels)
     nl = len(xs)
     bs, na, _, _, no = xs[0].shape
     for x in xs:
@@ -186,11 +186,12 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     ws = L.workspace(ws_bytes, dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
     with L.device_guard(dev):
-        L.check(lib.dh_yolo_decode_nms(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
-                                       float(conf_thres), float(iou_thres), int(multi_label), int(bool(agnostic)),
-                                       L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select), L.ptr(rows),
-                                       L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs),
-                                       L.c_void_p(meta.data_ptr() + 12 * bs), L.ptr(ws), ws_bytes, L.stream()),
+        entry = lib.dh_yolo_decode_nms_f16 if half else lib.dh_yolo_decode_nms     # fp16 maps are widened on load
+        L.check(entry(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
+                      float(conf_thres), float(iou_thres), int(multi_label), int(bool(agnostic)),
+                      L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select), L.ptr(rows),
+                      L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs),
+                      L.c_void_p(meta.data_ptr() + 12 * bs), L.ptr(ws), ws_bytes, L.stream()),
                 "dh_yolo_decode_nms")
     return rows, meta, cap
 

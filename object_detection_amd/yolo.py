@@ -76,7 +76,7 @@ def detect_decode(levels, anchors, stride):
     levels: list of (bs,na,ny,nx,no) tensors; anchors: (nl,na,2) in grid units; stride: (nl,).
     One kernel launch covers every level and writes the concatenated tensor directly.
     """
-    xs = [L.dev_f32(x, f"x[{i}]").contiguous() for i, x in enumerate(levels)]
+    xs, half = L.head_maps(levels)
     nl = len(xs)
     bs, na, _, _, no = xs[0].shape
     for x in xs:
@@ -92,8 +92,9 @@ def detect_decode(levels, anchors, stride):
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
     with L.device_guard(out.device):
         made_on = L.raw_stream()
-        L.check(L.lib().dh_yolo_decode(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
-                                       L.ptr(out), L.ptr(plane), L.ptr(logits), L.c_void_p(made_on)), "dh_yolo_decode")
+        entry = L.lib().dh_yolo_decode_f16 if half else L.lib().dh_yolo_decode     # fp16 maps are widened on load
+        L.check(entry(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
+                      L.ptr(out), L.ptr(plane), L.ptr(logits), L.c_void_p(made_on)), "dh_yolo_decode")
     # entries whose tensor has been freed go at once (they pin 8 bytes per anchor); the bound only guards against a
     # caller that keeps every decoded tensor alive
     for registry, dead in ((_OBJ_PLANES, lambda v: v[0]() is None), (_LOGIT_PLANES, lambda v: any(r() is None for r, _, _ in v[0]))):

@@ -70,7 +70,17 @@ def main():
             ms2, _ = wall(lambda: non_max_suppression(detect_decode(levels, anchors, strides), **kw), args.iters)
             ms1, _ = wall(lambda: detect_nms(levels, anchors, strides, **kw), args.iters)
             print(f"val   bs64@640 decode + NMS({name}): two calls {ms2:8.3f} ms, fused detect_nms {ms1:8.3f} ms", flush=True)
-        del levels, z
+        half = [x.half() for x in levels]
+        ms_h, _ = wall(lambda: detect_decode(half, anchors, strides), args.iters)
+        ms_c, _ = wall(lambda: detect_decode([h.float() for h in half], anchors, strides), args.iters)
+        ms_f, _ = wall(lambda: detect_decode(levels, anchors, strides), args.iters)
+        print(f"val   bs64@640 decode: fp16 maps read directly {ms_h:8.3f} ms, converted with .float() first {ms_c:8.3f} ms, "
+              f"fp32 maps {ms_f:8.3f} ms", flush=True)
+        for kw, name in ((dict(conf_thres=0.25, iou_thres=0.45), "0.25,0.45"), (dict(conf_thres=0.001, iou_thres=0.6, multi_label=True), "0.001,0.6,ml")):
+            ms_h, _ = wall(lambda: detect_nms(half, anchors, strides, **kw), args.iters)
+            ms_c, _ = wall(lambda: detect_nms([h.float() for h in half], anchors, strides, **kw), args.iters)
+            print(f"val   bs64@640 fused detect_nms({name}) on fp16 maps: read directly {ms_h:8.3f} ms, converted first {ms_c:8.3f} ms", flush=True)
+        del levels, z, half
     if "dense" in which:
         pred = dense_pred(32, 100000, 80, dev)
         ms, out = wall(lambda: non_max_suppression(pred, 0.25, 0.45, max_det=300), args.iters)
