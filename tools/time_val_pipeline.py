@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """One validation batch end to end on the device (object_detection/yolov5/val.py:194-232): loss on the raw maps, NMS at
-the validation thresholds, detection/label matching and the confusion matrix.  Wall clock, device-synchronised.
+the validation thresholds, detection/label matching and the confusion matrix; then the end of the run
+(val.py:253-257): ap_per_class on the statistics of --epoch-batches such batches, which never left the device.
+Wall clock, device-synchronised.
 
   python tools/time_val_pipeline.py [--batch 64] [--iters 10]
 """
@@ -20,10 +22,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--epoch-batches", type=int, default=78, help="batches whose statistics feed ap_per_class (78 x 64 = COCO val)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     from object_detection_amd.general import detect_nms, non_max_suppression, xywh2xyxy
-    from object_detection_amd.metrics import ConfusionMatrix
+    from object_detection_amd.metrics import ConfusionMatrix, ap_per_class
     from object_detection_amd.val import process_batches
     from object_detection_amd.yolo import detect_decode
     from object_detection_amd.yolo_loss import ComputeLoss
@@ -63,6 +66,22 @@ def main():
         n_correct = int(sum(int(c[:, 0].sum()) for c in correct))
         print(f"{'fused detect_nms' if fused else 'decode + NMS    '} + loss + matching + confusion matrix: {ms:7.3f} ms per batch of {bs} "
               f"({bs / ms * 1e3:9.0f} img/s); {sum(o.shape[0] for o in out)} detections, {n_correct} correct @0.5", flush=True)
+
+    # the statistics val.py appends per image (:231) stay on the device: (correct, conf, pred class) and the label classes
+    tp = torch.cat(correct)
+    det = torch.cat(out)
+    conf, pcls = det[:, 4], det[:, 5]
+    n = args.epoch_batches
+    jitter = torch.arange(n, device=dev, dtype=torch.float32)[:, None] * 1e-7        # distinct confidences per batch copy
+    stats = (tp.repeat(n, 1), (conf[None] - jitter).reshape(-1), pcls.repeat(n), targets[:, 1].double().repeat(n))
+    ap_per_class(*stats)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        res = ap_per_class(*stats)
+    ms = (time.perf_counter() - t0) / args.iters * 1e3
+    print(f"ap_per_class over {n} batches ({stats[0].shape[0]} detections, {stats[3].numel()} labels): {ms:7.3f} ms; "
+          f"mAP@0.5 {res[5][:, 0].mean():.4f}, mAP@0.5:0.95 {res[5].mean():.4f}", flush=True)
 
 
 if __name__ == "__main__":
