@@ -326,6 +326,22 @@ def main():
                 # (the event bracket above adds the two marker packets and the dispatch latency to it)
                 "rocprof_avg_launch_ms": round(pmc.get("per_launch", {}).get("k_yolo_decode", {}).get("avg_us", 0.0) / 1e3, 4) or None}
 
+    # the measured ceiling beside the nominal one: a plain device-to-device copy moving the same bytes as one decode
+    # launch (the same read + write mix), timed alone after the timed region
+    if rank == 0:
+        src_c = torch.empty(int(decode_bytes // 8), dtype=torch.float32, device=device)
+        dst_c = torch.empty_like(src_c)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            dst_c.copy_(src_c)
+        c0.record()
+        for _ in range(10):
+            dst_c.copy_(src_c)
+        c1.record()
+        torch.cuda.synchronize()
+        roofline["device_copy_gbs"] = round(decode_bytes * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+        del src_c, dst_c
+
     if rank == 0:
         line = {
             "metric": "images/sec decode+assign+IoU-loss+NMS, bs=64 @640px; HBM GB/s vs peak",
