@@ -40,15 +40,37 @@ __device__ __forceinline__ float conf_of_key(u64 key)
 }
 
 // ---- classes that have labels (np.unique(target_cls, return_counts=True), metrics.py:40) ---------------------------------
-__global__ void __launch_bounds__(256) k_ap_hist(const double* __restrict__ target_cls, long m, int class_cap,
-                                                 int* __restrict__ bins, int* __restrict__ meta)
+// Label classes repeat (tens of thousands of labels over a few dozen ids) and atomics on one global address serialise,
+// so a workgroup counts its AP_HIST_PER_THREAD * 1024 labels in an LDS histogram (ids below AP_HIST_LDS) first.
+#define AP_HIST_LDS 4096
+#define AP_HIST_PER_THREAD 8
+
+__global__ void __launch_bounds__(AP_THREADS) k_ap_hist(const double* __restrict__ target_cls, long m, int class_cap,
+                                                        int* __restrict__ bins, int* __restrict__ meta)
 {
-    const long i = blockIdx.x * 256l + threadIdx.x;
-    if (i >= m) return;
-    const double v = target_cls[i];
-    const int c = (int)v;
-    if (v == (double)c && c >= 0 && c < class_cap) atomicAdd(&bins[c], 1);
-    else atomicOr(&meta[1], 1);                                            // not an integer class id in range
+    __shared__ int s_bins[AP_HIST_LDS];
+    for (int i = threadIdx.x; i < AP_HIST_LDS; i += AP_THREADS) s_bins[i] = 0;
+    __syncthreads();
+    const long first = (long)blockIdx.x * (AP_THREADS * AP_HIST_PER_THREAD);
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < AP_HIST_PER_THREAD; ++k) {
+        const long i = first + k * AP_THREADS + threadIdx.x;
+        if (i >= m) continue;
+        const double v = target_cls[i];
+        const int c = (int)v;
+        if (v == (double)c && c >= 0 && c < class_cap) {
+            if (c < AP_HIST_LDS) atomicAdd(&s_bins[c], 1);
+            else atomicAdd(&bins[c], 1);
+        } else {
+            bad = true;                                                    // not an integer class id in range
+        }
+    }
+    if (bad) atomicOr(&meta[1], 1);
+    __syncthreads();
+    const int lim = class_cap < AP_HIST_LDS ? class_cap : AP_HIST_LDS;
+    for (int i = threadIdx.x; i < lim; i += AP_THREADS)
+        if (s_bins[i]) atomicAdd(&bins[i], s_bins[i]);
 }
 
 __global__ void __launch_bounds__(AP_THREADS) k_ap_unique(const int* __restrict__ bins, int class_cap, int* __restrict__ unique,
@@ -343,7 +365,8 @@ extern "C" int dh_ap_classes(const double* target_cls, int64_t m, int class_cap,
     if (hipMemsetAsync(bins, 0, sizeof(int) * class_cap, st) != hipSuccess) return DH_ERR_LAUNCH;
     if (hipMemsetAsync(meta, 0, sizeof(int) * 2, st) != hipSuccess) return DH_ERR_LAUNCH;
     if (m > 0)
-        hipLaunchKernelGGL(k_ap_hist, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, target_cls, (long)m, class_cap, bins, meta);
+        hipLaunchKernelGGL(k_ap_hist, dim3((unsigned)((m + AP_THREADS * AP_HIST_PER_THREAD - 1) / (AP_THREADS * AP_HIST_PER_THREAD))),
+                           dim3(AP_THREADS), 0, st, target_cls, (long)m, class_cap, bins, meta);
     hipLaunchKernelGGL(k_ap_unique, dim3(1), dim3(AP_THREADS), 0, st, bins, class_cap, unique, nt, meta);
     return dh_launch_status();
 }
