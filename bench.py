@@ -73,12 +73,21 @@ def synth_batch(bs, img, nc, nt, seed, device):
 def plant_objects(levels, targets, crit):
     """Raise obj / class logits on the cells the assignment selects, like a partly trained head."""
     tcls, _, indices, _ = crit.build_targets(levels, targets)
+    gen = torch.Generator(device=levels[0].device).manual_seed(77)
     for l, x in enumerate(levels):
         b, a, gj, gi = indices[l]
         if b.numel():
-            x[b, a, gj, gi, 4] = 1.5 + torch.randn(b.numel(), device=x.device)
-            x[b, a, gj, gi, 5 + tcls[l]] = 2.0 + torch.randn(b.numel(), device=x.device)
-            x[b, a, gj, gi, 0:4] *= 0.3
+            # one row per cell (several targets can share a cell: an indexed store with repeated indices keeps an
+            # arbitrary one), so that every run plants the same values
+            flat = ((b * x.shape[1] + a) * x.shape[2] + gj) * x.shape[3] + gi
+            order = torch.argsort(flat, stable=True)
+            keep = torch.ones_like(order, dtype=torch.bool)
+            keep[1:] = flat[order][1:] != flat[order][:-1]
+            sel = order[keep]
+            bb, aa, jj, ii, cc = b[sel], a[sel], gj[sel], gi[sel], tcls[l][sel]
+            x[bb, aa, jj, ii, 4] = 1.5 + torch.randn(sel.numel(), generator=gen, device=x.device)
+            x[bb, aa, jj, ii, 5 + cc] = 2.0 + torch.randn(sel.numel(), generator=gen, device=x.device)
+            x[bb, aa, jj, ii, 0:4] *= 0.3
     return sum(int(i[0].numel()) for i in indices)
 
 
