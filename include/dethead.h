@@ -270,6 +270,21 @@ int dh_ap_per_class(const unsigned char* tp, const float* conf, const float* pre
 int dh_anchor_metric(const float* wh, int64_t N, const float* k, int n, double thr, float* x, float* best, double* sums,
                      void* stream);
 
+/* LabelSmoothingFocalLoss.forward and its gradient (object_detection/loss.py:8-83; the CenterNet class loss of
+ * object_detection/train.py:147-153, called at detectors/centernet/loss.py:17).  logits (N, C, S) fp32 with the spatial
+ * axes flattened into S; one_hot != 0: labels (N, C, S), fp32 (label_i64 = 0) or int64 (label_i64 = 1), truncated to
+ * integers as .long() does; one_hot == 0: labels (N, S) int64 class indices with label smoothing and, when has_ignore,
+ * ignore_index.  out: 1 float (the mean over the N*S cells).  The forward leaves one byte per cell in the workspace
+ * (dh_focal_loss_workspace(N*S) bytes, device, 256-byte aligned) that the backward reads; grad_out is 1 device float,
+ * grad_logits (N, C, S) is written completely.  gamma >= 0; size_average and alpha have no effect in the reference. */
+size_t dh_focal_loss_workspace(int64_t cells);
+int dh_focal_loss_fwd(const float* logits, const void* labels, int64_t N, int C, int64_t S, int one_hot, int label_i64,
+                      double gamma, double smoothing, int has_ignore, int64_t ignore_index, float* out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int dh_focal_loss_bwd(const float* logits, const void* labels, int64_t N, int C, int64_t S, int one_hot, int label_i64,
+                      double gamma, double smoothing, int has_ignore, int64_t ignore_index, const float* grad_out,
+                      float* grad_logits, const void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,4 @@
-"""Drop-ins for object_detection/loss.py:102-166 (IoULossWithMask, bbox_iou on [...,4])."""
+"""Drop-ins for object_detection/loss.py: LabelSmoothingFocalLoss (:8-83), IoULossWithMask and bbox_iou on [...,4] (:102-166)."""
 import torch
 import torch.nn as nn
 
@@ -124,3 +124,79 @@ class IoULossWithMask(nn.Module):
 
     def forward(self, pred, target, mask):
         return _MaskedCIoULossPacked.apply(pred, target, mask)
+
+
+class _FocalLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, label, one_hot, gamma, smoothing, ignore_index):
+        x = L.dev_f32(logits, "logits").contiguous()                      # loss.py:42 (.float())
+        N, C = int(x.shape[0]), int(x.shape[1])
+        S = 1
+        for d in x.shape[2:]:
+            S *= int(d)
+        if not isinstance(label, torch.Tensor) or not label.is_cuda:
+            raise RuntimeError("LabelSmoothingFocalLoss: the label must be a tensor on the logits' ROCm device (no CPU fallback)")
+        # .long() (loss.py:43) happens on load: int64 labels are read as they are, everything else as fp32 and truncated
+        y = (label if label.dtype == torch.int64 else label.float()).contiguous()
+        want = tuple(x.shape) if one_hot else (N,)
+        if tuple(y.shape) != want:
+            raise RuntimeError(f"LabelSmoothingFocalLoss: label shape {tuple(y.shape)} does not match {want}")
+        lib = L.lib()
+        ws_bytes = lib.dh_focal_loss_workspace(N * S)
+        ws = L.workspace(ws_bytes, x.device)
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        args = (N, C, S, int(one_hot), int(y.dtype == torch.int64), float(gamma), float(smoothing),
+                int(ignore_index is not None), int(ignore_index) if ignore_index is not None else 0)
+        with L.device_guard(x.device):
+            L.check(lib.dh_focal_loss_fwd(L.ptr(x), L.ptr(y), *args, L.ptr(out), L.ptr(ws), ws_bytes, L.stream()),
+                    "dh_focal_loss_fwd")
+        ctx.save_for_backward(x, y, ws)
+        ctx.args, ctx.dtype = args, logits.dtype
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, y, ws = ctx.saved_tensors
+        g = grad_out.reshape(1).float().contiguous()
+        grad = torch.empty_like(x)
+        with L.device_guard(x.device):
+            L.check(L.lib().dh_focal_loss_bwd(L.ptr(x), L.ptr(y), *ctx.args, L.ptr(g), L.ptr(grad), L.ptr(ws), L.stream()),
+                    "dh_focal_loss_bwd")
+        return (grad if ctx.dtype == torch.float32 else grad.to(ctx.dtype)), None, None, None, None, None
+
+
+class LabelSmoothingFocalLoss(nn.Module):
+    """loss.py:8-83: the CenterNet class loss (object_detection/train.py:147-153 builds it with
+    one_hot_label_format=True, gamma=8).  Same constructor, same checks; as in the reference alpha and size_average are
+    stored and unused and the result is always the mean over cells.
+
+    One-hot labels are the (N, C, ...) target maps; index labels (N,) go with (N, C) logits (with more axes the
+    reference's own broadcast fails).  One forward launch streams the label maps once and touches the logits only at
+    labelled cells; the backward writes the dense gradient without reading the labels again.
+    """
+
+    def __init__(self, num_classes, one_hot_label_format=False, gamma=0, alpha=None, smoothing=0.0, size_average=True,
+                 ignore_index=None):
+        super().__init__()
+        self._num_classes = num_classes
+        self.one_hot_label_format = one_hot_label_format
+        self._gamma = gamma
+        self._alpha = alpha
+        self._smoothing = smoothing
+        self._size_average = size_average
+        self._ignore_index = ignore_index
+        if self._num_classes <= 1:
+            raise ValueError("The number of classes must be 2 or higher")
+        if self._gamma < 0:
+            raise ValueError("Gamma must be 0 or higher")
+
+    def forward(self, logits, label):
+        if logits.dim() < 2 or logits.dim() == 3:
+            raise RuntimeError("LabelSmoothingFocalLoss: logits must be (N, C) or (N, C, d1, d2, ...): with three axes the "
+                               "reference's softmax (loss.py:78) and log_softmax (loss.py:64) run over different axes")
+        if not self.one_hot_label_format and logits.dim() != 2:
+            raise RuntimeError("LabelSmoothingFocalLoss: index labels need (N, C) logits (loss.py:72-78 cannot broadcast others)")
+        if logits.shape[1] != self._num_classes and not self.one_hot_label_format:
+            raise RuntimeError(f"LabelSmoothingFocalLoss: {logits.shape[1]} logits per cell for {self._num_classes} classes")
+        return _FocalLoss.apply(logits, label, self.one_hot_label_format, self._gamma, self._smoothing,
+                                None if self.one_hot_label_format else self._ignore_index)

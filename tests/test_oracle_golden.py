@@ -345,3 +345,25 @@ def test_autoanchor_metric_oracle_vs_reference(golden, tag):
     bpr, aat = oaa.check_metric(k, wh, thr)
     fit = oaa.anchor_fitness(g[f"{tag}_k"], wh, 1 / thr)
     np.testing.assert_array_equal(np.array([bpr.item(), aat.item(), fit.item()], dtype=np.float32), g[f"{tag}_stats"])
+
+
+FOCAL_CASES = ("train", "g0", "g2", "flat", "idx", "idx_ignore", "idx_g0")
+
+
+def focal_kwargs(kw):
+    nc, one_hot, gamma, smoothing, ignore = kw
+    return dict(num_classes=int(nc), one_hot_label_format=bool(one_hot), gamma=float(gamma), smoothing=float(smoothing),
+                ignore_index=None if ignore < 0 else int(ignore))
+
+
+@pytest.mark.parametrize("tag", FOCAL_CASES)
+def test_focal_loss_oracle_vs_reference(golden, tag):
+    """loss.py:8-83: value and gradient of the reference's LabelSmoothingFocalLoss."""
+    from oracle import focal as of
+    g = golden("focal")
+    x = torch.from_numpy(g[f"{tag}_logits"]).requires_grad_(True)
+    loss = of.LabelSmoothingFocalLoss(**focal_kwargs(g[f"{tag}_kw"]))(x, torch.from_numpy(g[f"{tag}_label"]))
+    grad, = torch.autograd.grad(loss * 3.0, x)
+    # (the fixture was made with one torch thread: with more, the reductions inside softmax regroup by an ulp)
+    np.testing.assert_allclose(loss.detach().numpy(), g[f"{tag}_loss"], rtol=1e-6)
+    np.testing.assert_allclose(grad.numpy(), g[f"{tag}_grad"], rtol=1e-5, atol=1e-9)

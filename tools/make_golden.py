@@ -657,6 +657,50 @@ def gen_autoanchor():
     save("autoanchor", **out)
 
 
+def gen_focal(a_loss):
+    """object_detection/loss.py:8-83 from the untouched reference: value and gradient, one-hot target maps (the
+    CenterNet configuration of train.py:147-153) and index labels on 2-D logits."""
+    import warnings
+    from oracle import focal as of
+    rs = np.random.RandomState(31)
+    out = {}
+    cases = []
+    for tag, (N, C, W, H, gamma, n_obj) in {"train": (2, 20, 24, 20, 8.0, 14), "g0": (1, 3, 5, 7, 0.0, 4), "g2": (3, 6, 8, 8, 2.0, 9),
+                                            "flat": (5, 4, 0, 0, 1.5, 3)}.items():
+        shape = (N, C, W, H) if W else (N, C)
+        logits = f32(rs.normal(0, 2.0, shape))
+        label = np.zeros(shape, dtype=np.float32)
+        for _ in range(n_obj):
+            idx = tuple(rs.randint(0, d) for d in shape)
+            label[idx] = 1.0
+        if W:
+            label[0, 1, 2, 3] = 1.0
+            label[0, 2, 2, 3] = 1.0                                     # two classes at one cell
+            label[0, 0, 0, 0] = 0.7                                     # a fractional value: .long() makes it 0
+        cases.append((tag, dict(num_classes=C, one_hot_label_format=True, gamma=gamma, alpha=0.999, smoothing=0.1), logits, label))
+    for tag, (N, C, gamma, smoothing, ignore) in {"idx": (64, 7, 2.0, 0.1, None), "idx_ignore": (40, 5, 3.0, 0.0, 2),
+                                                   "idx_g0": (9, 3, 0, 0.2, None)}.items():
+        logits = f32(rs.normal(0, 2.0, (N, C)))
+        label = rs.randint(0, C, N).astype(np.int64)
+        cases.append((tag, dict(num_classes=C, gamma=gamma, smoothing=smoothing, ignore_index=ignore), logits, label))
+    for tag, kw, logits, label in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                             # implicit softmax dim (loss.py:78)
+            x = T(logits).requires_grad_(True)
+            want = a_loss.LabelSmoothingFocalLoss(**kw)(x, T(label))
+            gw, = torch.autograd.grad(want * 3.0, x)
+            x2 = T(logits).requires_grad_(True)
+            mine = of.LabelSmoothingFocalLoss(**kw)(x2, T(label))
+            gm, = torch.autograd.grad(mine * 3.0, x2)
+        assert torch.equal(want, mine) and torch.equal(gw, gm), tag
+        out[f"{tag}_logits"], out[f"{tag}_label"] = logits, label
+        out[f"{tag}_loss"], out[f"{tag}_grad"] = want.detach().numpy(), gw.numpy()
+        out[f"{tag}_kw"] = np.array([kw["num_classes"], int(kw.get("one_hot_label_format", False)), kw["gamma"], kw["smoothing"],
+                                     -1 if kw.get("ignore_index") is None else kw["ignore_index"]], dtype=np.float64)
+        print(f"  focal {tag}: loss {float(want):.6f}, |grad| {float(gw.abs().sum()):.4f}")
+    save("focal", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -665,7 +709,7 @@ def main():
     only = set(sys.argv[1:])
     if only:                      # e.g. `make_golden.py ap`: regenerate the named fixtures only
         gens = {"ap": lambda: gen_ap(y_metrics), "evalmatch": lambda: gen_evalmatch(y_metrics), "tta": gen_tta,
-                "autoanchor": gen_autoanchor}
+                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss)}
         for k in only:
             gens[k]()
         return
@@ -680,6 +724,7 @@ def main():
     gen_tta()
     gen_ap(y_metrics)
     gen_autoanchor()
+    gen_focal(a_loss)
 
 
 if __name__ == "__main__":

@@ -110,7 +110,27 @@ def main():
         print(f"centernet pool_nms         {us:9.1f} us  {2 * hb / us / 1e3:8.1f} GB/s (read + write the class maps)")
         us = timed(lambda: CN.decode_bbox(heat, size, off, 0.9), args.iters)
         print(f"centernet decode_bbox      {us:9.1f} us  {hb / us / 1e3:8.1f} GB/s (one read of the class maps; incl. the count copy)")
-        del heat, size, off
+        del size, off
+        # class loss of the CenterNet head (LabelSmoothingFocalLoss, one-hot maps, gamma 8): ~200 objects per image
+        from object_detection_amd.loss import LabelSmoothingFocalLoss
+        g = torch.Generator(device=dev).manual_seed(5)
+        logits = heat.requires_grad_(True)
+        label = torch.zeros_like(heat)
+        idx = [torch.randint(0, d, (200 * B,), generator=g, device=dev) for d in heat.shape]
+        label[idx[0], idx[1], idx[2], idx[3]] = 1.0
+        crit_cls = LabelSmoothingFocalLoss(num_classes=heat.shape[1], one_hot_label_format=True, gamma=8.0, smoothing=0.1)
+        us = timed(lambda: crit_cls(logits, label), args.iters)
+        print(f"centernet class loss fwd   {us:9.1f} us  {hb / us / 1e3:8.1f} GB/s (one read of the label maps)")
+
+        def fb_cls():
+            torch.autograd.grad(crit_cls(logits, label), logits)
+        us2 = timed(fb_cls, args.iters)
+        print(f"centernet class loss f+b   {us2:9.1f} us  bwd ~{us2 - us:8.1f} us {hb / (us2 - us) / 1e3:8.1f} GB/s (one write of the gradient maps)")
+        from oracle import focal as of       # the restatement in torch ops, run on the device: what the reference's code costs there
+        ref_cls = of.LabelSmoothingFocalLoss(num_classes=heat.shape[1], one_hot_label_format=True, gamma=8.0, smoothing=0.1)
+        us3 = timed(lambda: torch.autograd.grad(ref_cls(logits, label), logits), max(args.iters // 4, 2))
+        print(f"centernet class loss f+b   {us3:9.1f} us  as the reference's torch operations on the same device")
+        del heat, logits, label
         g = torch.Generator(device=dev).manual_seed(3)
         mask = (torch.rand((B, W, H), generator=g, device=dev) < 0.005).float()
         ls = torch.rand((B, 2, W, H), generator=g, device=dev) * 20 * mask[:, None]
