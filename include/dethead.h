@@ -285,6 +285,17 @@ int dh_focal_loss_bwd(const float* logits, const void* labels, int64_t N, int C,
                       double gamma, double smoothing, int has_ignore, int64_t ignore_index, const float* grad_out,
                       float* grad_logits, const void* workspace, void* stream);
 
+/* RegressionLossWithMask.forward and its gradient (object_detection/loss.py:86-100; the size / offset criteria that
+ * detectors/centernet/loss.py:19-21 calls when no box criterion is set).  pred, target (B, 2, S) and mask (B, S) fp32 with
+ * the spatial axes flattened into S; smooth != 0 selects smooth-L1 (beta 1).  out2: 2 device floats, the loss and its
+ * denominator sum(mask)*2 + 1e-4 (the backward reads it); grad_out 1 device float; grad_pred (B, 2, S) written completely.
+ * workspace: device, dh_regression_loss_workspace(B*S) bytes. */
+size_t dh_regression_loss_workspace(int64_t cells);
+int dh_regression_loss_fwd(const float* pred, const float* target, const float* mask, int64_t B, int64_t S, int smooth,
+                           float* out2, void* workspace, size_t workspace_bytes, void* stream);
+int dh_regression_loss_bwd(const float* pred, const float* target, const float* mask, int64_t B, int64_t S, int smooth,
+                           const float* out2, const float* grad_out, float* grad_pred, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

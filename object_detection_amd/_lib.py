@@ -76,6 +76,9 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_focal_loss_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_i64, c_int, c_int, c_double, c_double, c_int, c_i64,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dh_regression_loss_workspace": (c_size_t, [c_i64]),
+    "dh_regression_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_regression_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dh_anchor_metric": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dh_ap_classes": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dh_ap_per_class_workspace": (c_size_t, [c_i64, c_int]),

@@ -200,3 +200,49 @@ class LabelSmoothingFocalLoss(nn.Module):
             raise RuntimeError(f"LabelSmoothingFocalLoss: {logits.shape[1]} logits per cell for {self._num_classes} classes")
         return _FocalLoss.apply(logits, label, self.one_hot_label_format, self._gamma, self._smoothing,
                                 None if self.one_hot_label_format else self._ignore_index)
+
+
+class _RegressionLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, mask, smooth):
+        p = L.dev_f32(pred, "pred").contiguous()
+        t = L.dev_f32(target, "target").contiguous()
+        m = L.dev_f32(mask, "mask").contiguous()
+        if p.dim() != 4 or p.shape[1] != 2 or t.shape != p.shape or tuple(m.shape) != (p.shape[0], p.shape[2], p.shape[3]):
+            raise RuntimeError(f"RegressionLossWithMask: expected (B,2,W,H) pred/target and a (B,W,H) mask, got "
+                               f"{tuple(pred.shape)} / {tuple(target.shape)} / {tuple(mask.shape)}")
+        B, S = int(p.shape[0]), int(p.shape[2] * p.shape[3])
+        lib = L.lib()
+        ws_bytes = lib.dh_regression_loss_workspace(B * S)
+        ws = L.workspace(ws_bytes, p.device)
+        out2 = torch.empty(2, dtype=torch.float32, device=p.device)
+        with L.device_guard(p.device):
+            L.check(lib.dh_regression_loss_fwd(L.ptr(p), L.ptr(t), L.ptr(m), B, S, int(smooth), L.ptr(out2), L.ptr(ws), ws_bytes,
+                                               L.stream()), "dh_regression_loss_fwd")
+        ctx.save_for_backward(p, t, m, out2)
+        ctx.cfg = (B, S, int(smooth), pred.dtype)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        p, t, m, out2 = ctx.saved_tensors
+        B, S, smooth, dtype = ctx.cfg
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise RuntimeError("RegressionLossWithMask: gradients are provided for the predictions only")
+        g = grad_out.reshape(1).float().contiguous()
+        grad = torch.empty_like(p)
+        with L.device_guard(p.device):
+            L.check(L.lib().dh_regression_loss_bwd(L.ptr(p), L.ptr(t), L.ptr(m), B, S, smooth, L.ptr(out2), L.ptr(g), L.ptr(grad),
+                                                   L.stream()), "dh_regression_loss_bwd")
+        return (grad if dtype == torch.float32 else grad.to(dtype)), None, None, None
+
+
+class RegressionLossWithMask(nn.Module):
+    """loss.py:86-100: masked L1 (smooth=False) or smooth-L1 loss of the (B,2,W,H) size / offset maps."""
+
+    def __init__(self, smooth=False):
+        super().__init__()
+        self.smooth = smooth
+
+    def forward(self, pred, target, mask):
+        return _RegressionLoss.apply(pred, target, mask, self.smooth)

@@ -51,3 +51,19 @@ class LabelSmoothingFocalLoss(torch.nn.Module):
         if self._ignore_index is not None:
             loss[ignore] = 0                                            # loss.py:66-67
         return loss.mean()
+
+
+class RegressionLossWithMask(torch.nn.Module):
+    """object_detection/loss.py:86-100."""
+
+    def __init__(self, smooth=False):
+        super().__init__()
+        self.smooth = smooth
+
+    def forward(self, pred, target, mask):
+        pred = pred.permute(0, 2, 3, 1)                                  # loss.py:92-93
+        target = target.permute(0, 2, 3, 1)
+        expand_mask = torch.unsqueeze(mask, -1).repeat(1, 1, 1, 2)
+        loss_func = F.smooth_l1_loss if self.smooth else F.l1_loss      # loss.py:95-98
+        loss = loss_func(pred * expand_mask, target * expand_mask, reduction="sum")
+        return loss / (expand_mask.sum() + 1e-4)                         # loss.py:99-100

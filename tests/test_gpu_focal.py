@@ -97,3 +97,52 @@ def test_focal_loss_half_logits_and_errors():
         LabelSmoothingFocalLoss(num_classes=6)(d, torch.zeros(3, 8, 8, dtype=torch.int64).cuda())
     with pytest.raises(RuntimeError):
         LabelSmoothingFocalLoss(**kw)(d, label)                       # a CPU label
+
+
+@pytest.mark.parametrize("tag", ["reg_l1", "reg_smooth"])
+def test_regression_loss_golden(golden, tag):
+    from object_detection_amd.loss import RegressionLossWithMask
+    g = golden("focal")
+    x = torch.from_numpy(g[f"{tag}_pred"]).cuda().requires_grad_(True)
+    loss = RegressionLossWithMask(tag == "reg_smooth")(x, torch.from_numpy(g[f"{tag}_target"]).cuda(),
+                                                       torch.from_numpy(g[f"{tag}_mask"]).cuda())
+    grad, = torch.autograd.grad(loss * 2.0, x)
+    close(loss.item(), g[f"{tag}_loss"])
+    close(grad.cpu().numpy(), g[f"{tag}_grad"])
+
+
+def test_regression_loss_full_size_and_compute_losses():
+    """(B,2,160,160) maps against the oracle, and through compute_losses with criterion['box'] = None
+    (detectors/centernet/loss.py:18-21)."""
+    from object_detection_amd.centernet import compute_losses
+    from object_detection_amd.loss import LabelSmoothingFocalLoss, RegressionLossWithMask
+    rs = np.random.RandomState(12)
+    B, C, W, H = 4, 6, 160, 160
+    size_p, size_t = rs.uniform(0, 20, (B, 2, W, H)).astype(np.float32), rs.uniform(0, 20, (B, 2, W, H)).astype(np.float32)
+    off_p, off_t = rs.uniform(0, 1, (B, 2, W, H)).astype(np.float32), rs.uniform(0, 1, (B, 2, W, H)).astype(np.float32)
+    mask = (rs.rand(B, W, H) < 0.01).astype(np.float32)
+    cls_p = rs.normal(-2, 1, (B, C, W, H)).astype(np.float32)
+    cls_t = np.zeros((B, C, W, H), dtype=np.float32)
+    cls_t[:, 2] = mask
+    T = torch.from_numpy
+    for smooth in (False, True):
+        x = T(size_p).requires_grad_(True)
+        want = of.RegressionLossWithMask(smooth)(x, T(size_t), T(mask))
+        gw, = torch.autograd.grad(want, x)
+        d = T(size_p).cuda().requires_grad_(True)
+        got = RegressionLossWithMask(smooth)(d, T(size_t).cuda(), T(mask).cuda())
+        gg, = torch.autograd.grad(got, d)
+        close(got.item(), want.item())
+        close(gg.cpu().numpy(), gw.numpy())
+    crit = {"cls": LabelSmoothingFocalLoss(C, one_hot_label_format=True, gamma=2.0), "box": None,
+            "size": RegressionLossWithMask(False), "offset": RegressionLossWithMask(True)}
+    ocrit = {"cls": of.LabelSmoothingFocalLoss(C, one_hot_label_format=True, gamma=2.0), "box": None,
+             "size": of.RegressionLossWithMask(False), "offset": of.RegressionLossWithMask(True)}
+    losses, want = {}, {}
+    compute_losses([T(a).cuda() for a in (cls_p, size_p, off_p)], [T(a).cuda() for a in (cls_t, size_t, off_t, mask)], crit, losses)
+    want["cls"] = ocrit["cls"](T(cls_p), T(cls_t))
+    want["size"] = ocrit["size"](T(size_p), T(size_t), T(mask))
+    want["offset"] = ocrit["offset"](T(off_p), T(off_t), T(mask))
+    assert sorted(losses) == ["cls", "offset", "size"]
+    for k in want:
+        close(losses[k].item(), want[k].item())

@@ -367,3 +367,15 @@ def test_focal_loss_oracle_vs_reference(golden, tag):
     # (the fixture was made with one torch thread: with more, the reductions inside softmax regroup by an ulp)
     np.testing.assert_allclose(loss.detach().numpy(), g[f"{tag}_loss"], rtol=1e-6)
     np.testing.assert_allclose(grad.numpy(), g[f"{tag}_grad"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag", ["reg_l1", "reg_smooth"])
+def test_regression_loss_oracle_vs_reference(golden, tag):
+    """loss.py:86-100: RegressionLossWithMask value and gradient."""
+    from oracle import focal as of
+    g = golden("focal")
+    x = torch.from_numpy(g[f"{tag}_pred"]).requires_grad_(True)
+    loss = of.RegressionLossWithMask(tag == "reg_smooth")(x, torch.from_numpy(g[f"{tag}_target"]), torch.from_numpy(g[f"{tag}_mask"]))
+    grad, = torch.autograd.grad(loss * 2.0, x)
+    np.testing.assert_allclose(loss.detach().numpy(), g[f"{tag}_loss"], rtol=1e-6)
+    np.testing.assert_allclose(grad.numpy(), g[f"{tag}_grad"], rtol=1e-6, atol=1e-9)

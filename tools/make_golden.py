@@ -698,6 +698,23 @@ def gen_focal(a_loss):
         out[f"{tag}_kw"] = np.array([kw["num_classes"], int(kw.get("one_hot_label_format", False)), kw["gamma"], kw["smoothing"],
                                      -1 if kw.get("ignore_index") is None else kw["ignore_index"]], dtype=np.float64)
         print(f"  focal {tag}: loss {float(want):.6f}, |grad| {float(gw.abs().sum()):.4f}")
+    # RegressionLossWithMask (loss.py:86-100), L1 and smooth-L1
+    for tag, smooth in (("reg_l1", False), ("reg_smooth", True)):
+        B, W, H = 3, 12, 10
+        pred, target = f32(rs.normal(0, 2.0, (B, 2, W, H))), f32(rs.normal(0, 2.0, (B, 2, W, H)))
+        mask = (rs.rand(B, W, H) < 0.2).astype(np.float32)
+        pred[0, 0, 1, 1], target[0, 0, 1, 1], mask[0, 1, 1] = 1.5, 1.5, 1.0        # a zero difference inside the mask
+        pred[0, 1, 1, 1], target[0, 1, 1, 1] = 0.25, 1.25                          # exactly on the smooth-L1 knee
+        x = T(pred).requires_grad_(True)
+        want = a_loss.RegressionLossWithMask(smooth)(x, T(target), T(mask))
+        gw, = torch.autograd.grad(want * 2.0, x)
+        x2 = T(pred).requires_grad_(True)
+        mine = of.RegressionLossWithMask(smooth)(x2, T(target), T(mask))
+        gm, = torch.autograd.grad(mine * 2.0, x2)
+        assert torch.equal(want, mine) and torch.equal(gw, gm), tag
+        out[f"{tag}_pred"], out[f"{tag}_target"], out[f"{tag}_mask"] = pred, target, mask
+        out[f"{tag}_loss"], out[f"{tag}_grad"] = want.detach().numpy(), gw.numpy()
+        print(f"  {tag}: loss {float(want):.6f}")
     save("focal", **out)
 
 
