@@ -94,6 +94,9 @@ int dh_yolo_decode_f16(const void* const* level_ptrs, const int* ny, const int* 
  * the output is the first max_det kept rows in score order and a row's fate depends only on rows ranked above
  * it, so the result is exact whenever that prefix yields max_det rows.  needs_full[b] = 1 marks the images where it
  * did not (their output rows are incomplete): repeat the call with k_select = 0.  With k_select = 0 needs_full is all 0.
+ * k_select < 0: everything after the candidate search runs in one workgroup per image (three launches in all, for the
+ * usual few dozen candidates per image); needs max_det <= 1024, and an image with more than 1024 candidates sets
+ * needs_full[b] = 1 and gets no rows: repeat the call with k_select >= 0.
  * All of out, out_span, cand_count, needs_full (bs ints), workspace are device memory; workspace must be 256-byte aligned. */
 size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms);
 int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,

@@ -1019,6 +1019,152 @@ __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------ 2-6 in one workgroup
+// The usual inference case has a few dozen candidates per image: six launches of ~10 us each are then mostly launch
+// latency.  This kernel does everything after the prefilter for an image with at most SMALL_MAX candidates in one
+// workgroup and LDS only: sort the keys, fetch the boxes, greedy NMS in score order on boxes shifted by their class
+// offset (exactly what the reference hands to torchvision: general.py:720-722), first max_det kept rows out.
+// An image with more candidates sets needs_full and is left alone: the caller repeats the batch on the general path.
+#define SMALL_MAX 1024
+
+template <bool RAW, typename T = float>
+__global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, dh_fastdiv ncd, const u64* __restrict__ keys_all,
+                                                    int cap_pad, const int* __restrict__ counts, int cap, int agnostic,
+                                                    float max_wh, float thr, int max_det, float* __restrict__ out,
+                                                    int* __restrict__ cursor, int2* __restrict__ out_span,
+                                                    int* __restrict__ cand_count, int* __restrict__ needs_full)
+{
+    __shared__ u64 s_key[SMALL_MAX];
+    __shared__ float4 s_box[SMALL_MAX];         // unshifted x1,y1,x2,y2 in score order
+    __shared__ float s_off[SMALL_MAX];          // class * max_wh (0 when agnostic)
+    __shared__ float4 kbox[SMALL_MAX];          // kept boxes (shifted)
+    __shared__ float karea[SMALL_MAX];
+    __shared__ unsigned char s_keep[SMALL_MAX];
+    __shared__ u64 sup_mask[16], cmask[64];
+    __shared__ float4 cbox[64];
+    __shared__ float carea[64];
+    __shared__ int s_kept, s_base, wcount[16];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_all = counts[b];
+    if (threadIdx.x == 0) cand_count[b] = n_all;
+    if (n_all > SMALL_MAX || n_all > cap) {                         // workgroup-uniform
+        if (threadIdx.x == 0) { needs_full[b] = 1; out_span[b] = make_int2(0, 0); }
+        return;
+    }
+    const int n = n_all;
+    // sort by score (descending scores are ascending keys)
+    const uint32_t npad = pow2_ceil((uint32_t)(n < 2 ? 2 : n));
+    for (uint32_t i = threadIdx.x; i < npad; i += 1024) s_key[i] = (int)i < n ? keys_all[(size_t)b * cap_pad + i] : KEY_SENTINEL;
+    s_keep[threadIdx.x] = 0;
+    __syncthreads();
+    bitonic_lds(s_key, npad, 0, 2, npad);
+    // fetch the boxes (general.py:553-560 xywh -> xyxy on the decoded row)
+    const int no = (int)ncd.d + 5;
+    if ((int)threadIdx.x < n) {
+        const uint32_t ord = (uint32_t)s_key[threadIdx.x];
+        const uint32_t anchor = dh_div(ord, ncd);
+        const uint32_t cls = ord - anchor * ncd.d;
+        float x, y, w, h;
+        if (RAW) {
+            const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
+            const decode_level& L = S.lvl[rr.l];
+            x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p + 0)));
+            y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + 1)));
+            w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2)));
+            h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3)));
+        } else {
+            const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
+            x = p[0]; y = p[1]; w = p[2]; h = p[3];
+        }
+        s_box[threadIdx.x] = make_float4(x - w / 2, y - h / 2, x + w / 2, y + h / 2);
+        s_off[threadIdx.x] = agnostic ? 0.0f : (float)cls * max_wh;                      // general.py:720
+    }
+    __syncthreads();
+    // greedy NMS in score order, 64 candidates at a time (the scheme of k_nms_greedy, whole-image mode)
+    int kept = 0;
+    for (int base = 0; base < n && kept < max_det; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < n;
+        box_t bx = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            const float4 v = s_box[p];
+            const float c = s_off[p];
+            bx.x1 = v.x + c; bx.y1 = v.y + c; bx.x2 = v.z + c; bx.y2 = v.w + c;          // general.py:721
+        }
+        const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
+        bool sup = false;
+        for (int k = wave; k < kept; k += 16) {
+            const float4 kb = kbox[k];
+            const box_t kbb = {kb.x, kb.y, kb.z, kb.w};
+            sup = sup || suppresses(kbb, karea[k], bx, area, thr);
+        }
+        const u64 sm = __ballot(sup);
+        if (lane == 0) sup_mask[wave] = sm;
+        if (wave == 0) { cbox[lane] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2); carea[lane] = area; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = wave * 4 + q;
+            const float4 bi4 = cbox[i];
+            const box_t bi = {bi4.x, bi4.y, bi4.z, bi4.w};
+            const bool hit = (lane > i) && suppresses(bi, carea[i], bx, area, thr);
+            const u64 hm = __ballot(hit);
+            if (lane == 0) cmask[i] = hm;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            u64 dead = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) dead |= sup_mask[w];
+            u64 todo = __ballot(valid) & ~dead;
+            u64 kept_mask = 0;
+            int room = max_det - kept;
+            while (todo && room > 0) {
+                const int i = __ffsll((long long)todo) - 1;
+                kept_mask |= 1ull << i;
+                todo &= ~(cmask[i] | (1ull << i));
+                --room;
+            }
+            if ((kept_mask >> lane) & 1ull) {
+                const int slot = kept + __popcll(kept_mask & lanemask_lt());
+                s_keep[p] = 1;
+                kbox[slot] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+                karea[slot] = area;
+            }
+            if (lane == 0) s_kept = kept + __popcll(kept_mask);
+        }
+        __syncthreads();
+        kept = s_kept;
+    }
+    // the kept rows, in score order, into this image's span of the packed output
+    const int total = kept < max_det ? kept : max_det;
+    if (threadIdx.x == 0) {
+        const int first = atomicAdd(cursor, total);
+        s_base = first;
+        out_span[b] = make_int2(first, total);
+        needs_full[b] = 0;
+    }
+    const bool k = (int)threadIdx.x < n && s_keep[threadIdx.x] != 0;
+    const u64 bm = __ballot(k);
+    if (lane == 0) wcount[wave] = __popcll(bm);
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) if (w < wave) before += wcount[w];
+    const int pos = before + __popcll(bm & lanemask_lt());
+    if (k && pos < total) {
+        const u64 key = s_key[threadIdx.x];
+        const uint32_t ord = (uint32_t)key;
+        const uint32_t anchor = dh_div(ord, ncd);
+        const float4 v = s_box[threadIdx.x];
+        float* __restrict__ o = out + ((size_t)s_base + pos) * 6;
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        o[4] = key_score((uint32_t)(key >> 32));
+        o[5] = (float)(ord - anchor * ncd.d);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ grouped rows (CenterNet)
 // Ready-made detection rows [x1,y1,x2,y2,conf,cls] of several images (image b = count[b] rows from row first[b])
 // instead of a prediction tensor: keys from the row's own score (or none: input order), gather by row index, and a collect
@@ -1262,6 +1408,14 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     else { if (raw) DH_PREFILTER_N(false, true, float); else DH_PREFILTER_N(false, false, float); }
 #undef DH_PREFILTER_N
 #undef DH_PREFILTER
+    if (k_select < 0) {      // one workgroup per image does the rest; images with too many candidates set needs_full
+        if (max_det > SMALL_MAX) return DH_ERR_ARG;
+        const float off = agnostic ? 0.0f : (float)max_wh;
+#define DH_SMALL(R, T) hipLaunchKernelGGL((k_nms_small<R, T>), dim3(bs), dim3(1024), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad, counts, cap, agnostic, off, thr, max_det, out, cursor, (int2*)out_span, cand_count, needs_full)
+        if (raw && half) DH_SMALL(true, _Float16); else if (raw) DH_SMALL(true, float); else DH_SMALL(false, float);
+#undef DH_SMALL
+        return dh_launch_status();
+    }
     // score order: either the best k_target rows per image (select + sort in LDS) or all of them
     const u64* ranked = keys;
     int ranked_pad = L.cap_pad;

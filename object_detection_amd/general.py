@@ -9,6 +9,29 @@ from .yolo import _anchor_pixels, objectness_plane
 MAX_WH = 7680      # general.py:663
 MAX_NMS = 30000    # general.py:664
 K_SELECT = 3840    # candidates per image that go through NMS on the first attempt (0: all); see nms_launch
+K_SMALL = -1       # k_select value: everything after the prefilter in one workgroup per image (<= SMALL_MAX candidates each)
+SMALL_MAX = 1024   # what that workgroup holds (SMALL_MAX of csrc/nms.hip)
+SMALL_BELOW = 768  # candidate count of the busiest image up to which the next call of the same kind tries the small path
+
+# Which first attempt to make is a guess about the data, so it is made from the last call of the same kind (same shape,
+# thresholds and options): a detector at its usual confidence threshold leaves a few dozen candidates per image, every
+# time, and a validation pass at conf 0.001 thousands, every time.  A wrong guess costs a repeat on the general path.
+_SMALL_HINT = {}
+
+
+def _first_attempt(key, max_det, k_select):
+    if k_select is not None:
+        return int(k_select)
+    return K_SMALL if (max_det <= SMALL_MAX and _SMALL_HINT.get(key, False)) else K_SELECT
+
+
+def _remember(rows, key, used):
+    rows._dh_attempt = (key, used)          # read back by nms_views, which sees the candidate counts
+
+
+def _next_attempt(rows):
+    """After needs_full: the small attempt is followed by the prefix selection, that one by the full sort."""
+    return K_SELECT if getattr(rows, "_dh_attempt", (None, 0))[1] < 0 else 0
 
 
 def _convert(x, mode):
@@ -99,7 +122,7 @@ def _with_apriori_labels(pred, labels, nc):
 
 
 def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-               labels=(), max_det=300, cap=None, k_select=K_SELECT):
+               labels=(), max_det=300, cap=None, k_select=None):
     """Enqueue the whole NMS pipeline; nothing is copied to the host (safe inside HIP graph capture).
 
     Returns (rows, meta, cap): rows (bs*max_det, 6) packed detections, meta int32 [bs x {first row, row
@@ -109,6 +132,9 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     k_select > 0: only the best-scoring k_select candidates of each image (at least 8*max_det) are sorted and go
     through NMS, which is exact whenever they yield max_det rows (a row's fate depends only on rows ranked above
     it); images where they do not are flagged in meta and nms_views asks for a repeat with k_select=0.
+    k_select = K_SMALL: one workgroup per image does everything after the prefilter (three launches instead of
+    seven); images with more than SMALL_MAX candidates are flagged the same way.  k_select = None picks K_SMALL
+    when the last call of the same kind stayed below SMALL_BELOW candidates per image, K_SELECT otherwise.
     """
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
@@ -135,6 +161,9 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     meta = torch.empty(4 * bs, dtype=torch.int32, device=dev)
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
+    key = ("nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
+    k_select = _first_attempt(key, max_det, k_select)
+    _remember(rows, key, k_select)
     with L.device_guard(dev):
         L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
                                    int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select),
@@ -154,7 +183,7 @@ def _class_keep(classes, nc, dev):
 
 
 def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                      multi_label=False, max_det=300, cap=None, k_select=K_SELECT):
+                      multi_label=False, max_det=300, cap=None, k_select=None):
     """nms_launch fed by the raw head maps: the same (rows, meta, cap) as
     nms_launch(detect_decode(levels, anchors, stride), ...), without writing or reading the decoded tensor."""
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
@@ -185,6 +214,9 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
+    key = ("detect_nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
+    k_select = _first_attempt(key, max_det, k_select)
+    _remember(rows, key, k_select)
     with L.device_guard(dev):
         entry = lib.dh_yolo_decode_nms_f16 if half else lib.dh_yolo_decode_nms     # fp16 maps are widened on load
         L.check(entry(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
@@ -201,7 +233,7 @@ def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes
     """non_max_suppression(Detect(x)[0], ...) (val.py:194,203; detect.py:126,132) straight from the raw head maps
     `levels` (list of (bs,na,ny,nx,5+nc)); anchors / stride as Detect holds them.  Bit-identical to the two-call
     sequence, at about half its HBM traffic: the decoded (bs, A, 5+nc) tensor is neither written nor read."""
-    cap, k_select = None, K_SELECT
+    cap, k_select = None, None
     while True:
         rows, meta, cap = detect_nms_launch(levels, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
                                             max_det, cap, k_select)
@@ -211,7 +243,7 @@ def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes
         if result is not None:
             return result
         if need < 0:
-            k_select = 0
+            k_select = _next_attempt(rows)
         else:
             cap = need
 
@@ -236,8 +268,14 @@ def nms_views(rows, host, cap):
     (None, needed_cap) when the candidate capacity overflowed, (None, -1) when some image needs the full sort
     (see nms_launch): the caller repeats the launch with that cap, or with k_select=0."""
     bs = len(host) // 4
-    if max(host[2 * bs:3 * bs]) > cap:
-        return None, max(host[2 * bs:3 * bs])
+    busiest = max(host[2 * bs:3 * bs])
+    key = getattr(rows, "_dh_attempt", (None, 0))[0]
+    if key is not None:
+        if len(_SMALL_HINT) > 64:
+            _SMALL_HINT.clear()
+        _SMALL_HINT[key] = busiest <= SMALL_BELOW
+    if busiest > cap:
+        return None, busiest
     if any(host[3 * bs:]):
         return None, -1
     # images are packed in completion order: one split() call makes every per-image view
@@ -263,7 +301,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     of the per-image counts; the returned tensors are views of one packed buffer.
     The reference's 10 s wall-clock bail-out (general.py:734-736) is not reproduced.
     """
-    cap, k_select = None, K_SELECT
+    cap, k_select = None, None
     while True:
         rows, meta, cap = nms_launch(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det, cap,
                                      k_select)
@@ -273,6 +311,6 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         if result is not None:
             return result
         if need < 0:
-            k_select = 0      # the best-scoring prefix did not yield max_det rows somewhere: sort everything
+            k_select = _next_attempt(rows)      # the attempt did not cover some image: the next, more general one
         else:
             cap = need        # multi-label produced more candidates than rows: rerun with room for all of them
