@@ -155,6 +155,12 @@ class ConfusionMatrix:
         fp = m.sum(1) - tp
         return tp[:-1], fp[:-1]
 
+    def print(self):
+        """metrics.py:196-198: one line per row of the matrix."""
+        m = self.matrix
+        for i in range(self.nc + 1):
+            print(' '.join(map(str, m[i])))
+
 
 AP_CLASS_CAP = 1 << 16      # class ids are integers in [0, AP_CLASS_CAP)
 
@@ -163,6 +169,19 @@ def fitness(x):
     """Weighted combination of [P, R, mAP@0.5, mAP@0.5:0.95] (metrics.py:15-18); host arithmetic on a (k, >=4) array."""
     w = [0.0, 0.0, 0.1, 0.9]
     return (x[:, :4] * w).sum(1)
+
+
+def compute_ap(recall, precision):
+    """AP of one precision / recall curve -> (ap, mpre, mrec) (metrics.py:89-114, method 'interp').  Host arithmetic on
+    the small numpy curves it is given, as in the reference; ap_per_class computes the same thing on the device for every
+    class and IoU threshold at once and does not go through here."""
+    mrec = np.concatenate(([0.0], recall, [1.0]))
+    mpre = np.concatenate(([1.0], precision, [0.0]))
+    mpre = np.flip(np.maximum.accumulate(np.flip(mpre)))           # precision envelope
+    x = np.linspace(0, 1, 101)                                      # 101-point interpolation (COCO)
+    y = np.interp(x, mrec, mpre)
+    ap = (np.diff(x) * (y[1:] + y[:-1]) / 2.0).sum()                # the trapezoid rule written out
+    return ap, mpre, mrec
 
 
 def _to_device(a, dtype, device, name):

@@ -48,3 +48,17 @@ def test_bench_cpu_baseline_leg_runs_on_the_oracle():
     out = bench.cpu_baseline(seconds_budget=0.2)
     assert out["kind"] == "port" and out["unit"] == "images/s" and out["value"] > 0 and out["cores"] >= 1
     assert "bs 8" in out["sample"]
+
+
+def test_host_side_metric_helpers_match_the_oracle():
+    """compute_ap and fitness are host arithmetic by interface (numpy curves in, numbers out)."""
+    import numpy as np
+    from object_detection_amd.metrics import compute_ap, fitness
+    from oracle import ap as oa
+    rs = np.random.RandomState(0)
+    recall = np.sort(rs.rand(50))
+    precision = np.sort(rs.rand(50))[::-1]
+    got, want = compute_ap(recall, precision), oa.compute_ap(recall, precision)
+    assert got[0] == want[0] and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    x = rs.rand(4, 7)
+    assert np.array_equal(fitness(x), oa.fitness(x))
