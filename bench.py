@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2, 3),
                     help="1: everything on one stream; 2: the NMS chain on a second stream; 3: NMS chain and loss on their own streams")
+    ap.add_argument("--early-positives", action="store_true",
+                    help="target assignment and the positives' forward on a side stream beside the decode (they read only "
+                         "the targets and the raw maps); measured slower than keeping them on the main stream")
     ap.add_argument("--autograd", action="store_true",
                     help="call loss = crit(p, t); autograd.grad(loss, p) instead of crit.forward_backward(p, t): same kernels, "
                          "plus the autograd engine's hop to its device thread and back (two thread wake-ups per step)")
@@ -212,6 +215,8 @@ def main():
     main_stream = torch.cuda.current_stream()
     nms_stream = torch.cuda.Stream() if overlap else main_stream
     loss_stream = torch.cuda.Stream() if n_streams == 3 else main_stream
+    early = overlap and not args.autograd and args.early_positives
+    pos_stream = torch.cuda.Stream() if early else None
     set_stream = torch.cuda.set_stream
 
     def launch(record, detail=False):
@@ -223,6 +228,13 @@ def main():
         marks = mark_pool.pop() if record else None
         detail = detail and record
         h0 = time.perf_counter()
+        positives = pos_done = None
+        if early:      # assignment + positives' forward beside the decode: short kernels that read ~2 MB of the raw maps
+            set_stream(pos_stream)
+            positives = crit.positives(p, targets)
+            pos_done = torch.cuda.Event()
+            pos_done.record()
+            set_stream(main_stream)
         if record: marks[0].record()
         z = f_decode()
         if record: marks[1].record()
@@ -234,7 +246,12 @@ def main():
                 loss_stream.wait_event(decoded)
                 set_stream(loss_stream)
         if detail: marks[6].record()
-        loss, items, grads, stats = f_loss()
+        if early:
+            torch.cuda.current_stream().wait_event(pos_done)
+            loss, items, grads = crit.forward_backward(p, targets, positives=positives)
+            stats = crit.last_stats
+        else:
+            loss, items, grads, stats = f_loss()
         if detail: marks[2].record()
         h2 = time.perf_counter()
         if overlap:
@@ -368,7 +385,9 @@ def main():
                 ("p10", "p50", "p90", "max", "argmax"), list(np.percentile(np.diff(step_wall), (10, 50, 90, 100))) +
                 [int(np.argmax(np.diff(step_wall))) * 1e-3])} if len(step_wall) > 2 else None,
             "collective": "one all_reduce(SUM) of [lbox, lobj, lcls, n_pos] per step over RCCL, on the side stream" if world > 1 else None,
-            "loss_call": "crit(p,t) + torch.autograd.grad" if args.autograd else "crit.forward_backward(p,t)",
+            "loss_call": "crit(p,t) + torch.autograd.grad" if args.autograd else (
+                "crit.positives(p,t) on a side stream beside the decode, then crit.forward_backward(p,t,positives=...)" if early
+                else "crit.forward_backward(p,t)"),
             "streams": {1: "one stream", 2: "decode, assign+loss | nms chain on two streams (stage_ms overlap)",
                         3: "decode | nms chain | assign+loss on three streams (stage_ms overlap)"}[n_streams],
             "roofline": roofline,

@@ -194,6 +194,21 @@ int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const float* anchors,
                          int64_t* tcls, int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits,
                          const float* grad_loss, float* const* grad_p, float* out, void* assign_workspace,
                          size_t assign_workspace_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* dh_yolo_loss_fwd_bwd in two halves, for callers that can start the first one early.  dh_yolo_loss_positives: target
+ * assignment (loss.py:169-222) and the forward of the assigned rows (loss.py:126-150) -- they read only the targets and
+ * the raw maps, so they may run on another stream beside whatever produces or decodes the maps.  dh_yolo_loss_dense: the
+ * dense objectness forward (loss.py:152-156), the whole backward and the reduction into out.  Same arguments, buffers and
+ * workspaces as dh_yolo_loss_fwd_bwd; the caller orders the second call after the first (same stream, or an event). */
+int dh_yolo_loss_positives(const float* targets, int64_t nt, const float* anchors, double anchor_t, const float* const* p,
+                           const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t* idx, float* tbox,
+                           float* anch, int64_t* tcls, int* counts, int64_t cap, const dh_yolo_hyp* hyp,
+                           void* assign_workspace, size_t assign_workspace_bytes, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int dh_yolo_loss_dense(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc, const int64_t* idx,
+                       const float* tbox, const float* anch, const int64_t* tcls, const int* counts, int64_t cap,
+                       const dh_yolo_hyp* hyp, const float* obj_logits, const float* grad_loss, float* const* grad_p,
+                       float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 
 /* N x M IoU of xyxy boxes, no eps (object_detection/yolov5/utils/metrics.py:242-264) and of
  * (w,h) pairs (metrics.py:291-296).  out is (N,M) row-major. */

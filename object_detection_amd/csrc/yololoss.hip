@@ -433,8 +433,10 @@ namespace {
 
 // forward launches; fill: set the owner map (and the two counters behind it) to -1 here, false when the caller's
 // assignment launch already did; final: run the reduction as a launch of its own
+// parts: 1 = positives, 2 = dense objectness (+ final), 3 = both
 int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx, const float* tbox, const float* anch,
-               const int64_t* tcls, const int* counts, const float* obj_logits, float* out, bool fill, bool final, hipStream_t st)
+               const int64_t* tcls, const int* counts, const float* obj_logits, float* out, bool fill, bool final, hipStream_t st,
+               int parts = 3)
 {
     int* owner = (int*)(ws + W.off_owner);
     float* iou_ws = (float*)(ws + W.off_iou);
@@ -444,9 +446,10 @@ int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx,
     // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
     // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
     if (fill && hipMemsetAsync(owner, 0xFF, W.off_iou - W.off_owner, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (P.cap > 0)
+    if (P.cap > 0 && (parts & 1))
         hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
                            anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+    if (!(parts & 2)) return dh_launch_status();
     hipLaunchKernelGGL(k_yl_obj_fwd, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
                        (float*)(ws + W.off_dobj), obj_logits);
     if (final)
@@ -542,6 +545,54 @@ extern "C" int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const floa
     rc = launch_fwd(P, W, ws, idx, tbox, anch, tcls, counts, obj_logits, out, false, false, (hipStream_t)stream);
     if (rc != DH_OK) return rc;
     // 4 dense gradient, whose workgroup 0 also does the forward's reduction, 5 positives' gradient
+    const yl_final_args F = {counts, (const float*)(ws + W.off_iou), (const float*)(ws + W.off_cls),
+                             (const double*)(ws + W.off_partial), (const int*)(ws + W.off_invalid), out};
+    return launch_bwd(Pb, Wb, ws, idx, tbox, anch, tcls, counts, grad_loss, grad_p, &F, (hipStream_t)stream);
+}
+
+// The fused entry in two halves, for callers that can start the first one early: assignment and the positives' forward
+// only read the targets and the raw maps, so they can be enqueued on another stream beside whatever produces or decodes
+// the maps; the second half (dense objectness forward, the whole backward, the reduction) follows on the stream that
+// holds the objectness logits.  Same arguments and workspaces as dh_yolo_loss_fwd_bwd; the caller orders the two calls
+// (an event between the streams).
+extern "C" int dh_yolo_loss_positives(const float* targets, int64_t nt, const float* anchors, double anchor_t,
+                                      const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                      int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
+                                      const dh_yolo_hyp* hyp, void* assign_workspace, size_t assign_workspace_bytes,
+                                      void* workspace, size_t workspace_bytes, void* stream)
+{
+    yl_params P;
+    yl_ws W;
+    if (!p || !hyp || !counts || !workspace) return DH_ERR_ARG;
+    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W)) return DH_ERR_ARG;
+    for (int l = 0; l < nl; ++l) if (!p[l]) return DH_ERR_ARG;
+    if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
+    if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && !dh_aligned16(tbox))) return DH_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    const int rc = dh_launch_build_targets(targets, nt, anchors, nl, na, ny, nx, anchor_t, cap, idx, tbox, anch, tcls, counts,
+                                           assign_workspace, assign_workspace_bytes, ws + W.off_owner, W.off_iou - W.off_owner, stream);
+    if (rc != DH_OK) return rc;
+    return launch_fwd(P, W, ws, idx, tbox, anch, tcls, counts, nullptr, nullptr, false, false, (hipStream_t)stream, 1);
+}
+
+extern "C" int dh_yolo_loss_dense(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                  const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
+                                  int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, const float* grad_loss,
+                                  float* const* grad_p, float* out, void* workspace, size_t workspace_bytes, void* stream)
+{
+    yl_params P, Pb;
+    yl_ws W, Wb;
+    if (!p || !grad_p || !hyp || !out || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
+    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W)) return DH_ERR_ARG;
+    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, Pb, Wb)) return DH_ERR_ARG;
+    for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
+    if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
+    if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    const int rc = launch_fwd(P, W, ws, idx, tbox, anch, tcls, counts, obj_logits, out, false, false, (hipStream_t)stream, 2);
+    if (rc != DH_OK) return rc;
     const yl_final_args F = {counts, (const float*)(ws + W.off_iou), (const float*)(ws + W.off_cls),
                              (const double*)(ws + W.off_partial), (const int*)(ws + W.off_invalid), out};
     return launch_bwd(Pb, Wb, ws, idx, tbox, anch, tcls, counts, grad_loss, grad_p, &F, (hipStream_t)stream);

@@ -147,6 +147,76 @@ def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss):
     return A, out, grads
 
 
+class _Positives:
+    """What ComputeLoss.positives leaves behind for forward_backward: the assignment, the loss workspace with the
+    positives' forward results in it, and the stream it was made on."""
+    __slots__ = ("assign", "ws", "aws", "hyp", "maps_key", "made_on")
+
+    def borrow(self):
+        """About to be used on the current stream: keep the allocator from recycling the buffers before that stream is done."""
+        dev = self.ws.device
+        if L._raw_stream(dev.index) != self.made_on:
+            cur = torch.cuda.current_stream(dev)
+            A = self.assign
+            for t in (self.ws, self.aws, A.idx, A.tbox, A.anch, A.tcls, A.counts):
+                t.record_stream(cur)
+
+
+def _loss_positives(shapes, targets, anchors, anchor_t, hyp, nc, maps):
+    """First half of _loss_fused: assignment and the forward of the assigned rows (reads only targets and maps)."""
+    tg = L.dev_f32(targets, "targets").contiguous()
+    if tg.dim() != 2 or tg.shape[1] != 6:
+        raise RuntimeError(f"targets must be (nt,6) [image,class,x,y,w,h], got {tuple(targets.shape)}")
+    anc = L.dev_f32(anchors, "anchors").contiguous()
+    nl, na = int(anc.shape[0]), int(anc.shape[1])
+    dev = maps[0].device
+    A = _Assignment(shapes, tg.shape[0], na, nl, dev)
+    bs = int(maps[0].shape[0])
+    for x, ny_, nx_ in zip(maps, A.ny, A.nx):
+        if tuple(x.shape) != (bs, na, ny_, nx_, nc + 5):
+            raise RuntimeError(f"ComputeLoss: level shape {tuple(x.shape)} does not match (bs,na,ny,nx,5+nc)")
+    lib = L.lib()
+    ny, nx = L.int_array(A.ny), L.int_array(A.nx)
+    aws_bytes = lib.dh_build_targets_workspace(nl, na, A.nt)
+    ws_bytes = lib.dh_yolo_loss_workspace(ny, nx, nl, bs, na, nc, A.cap)
+    if ws_bytes == 0:
+        raise RuntimeError("ComputeLoss: unsupported problem size (a level exceeds 2^32 elements)")
+    st = _Positives()
+    st.assign, st.hyp = A, hyp
+    st.aws, st.ws = L.workspace(aws_bytes, dev), L.workspace(ws_bytes, dev)
+    st.maps_key = [(x.data_ptr(), tuple(x.shape)) for x in maps]
+    ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
+    with L.device_guard(dev):
+        st.made_on = L.raw_stream()
+        L.check(lib.dh_yolo_loss_positives(L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc,
+                                           L.ptr(A.idx), L.ptr(A.tbox), L.ptr(A.anch), L.ptr(A.tcls), L.ptr(A.counts), A.cap,
+                                           ctypes.byref(hyp), L.ptr(st.aws), aws_bytes, L.ptr(st.ws), ws_bytes,
+                                           L.c_void_p(st.made_on)), "dh_yolo_loss_positives")
+    return st
+
+
+def _loss_dense(st, nc, maps, grad_loss):
+    """Second half of _loss_fused on the current stream; returns (out, grads)."""
+    if st.maps_key != [(x.data_ptr(), tuple(x.shape)) for x in maps]:
+        raise RuntimeError("positives= was not produced by ComputeLoss.positives for these maps")
+    st.borrow()
+    A = st.assign
+    nl = len(maps)
+    bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
+    dev = maps[0].device
+    out = torch.empty(6 + nl, dtype=torch.float32, device=dev)
+    grads = [torch.empty_like(x) for x in maps]
+    ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
+    gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
+    logits = objectness_logits(maps)
+    with L.device_guard(dev):
+        L.check(L.lib().dh_yolo_loss_dense(ptrs, L.int_array(A.ny), L.int_array(A.nx), nl, bs, na, nc, L.ptr(A.idx), L.ptr(A.tbox),
+                                           L.ptr(A.anch), L.ptr(A.tcls), L.ptr(A.counts), A.cap, ctypes.byref(st.hyp),
+                                           L.ptr(logits), L.ptr(grad_loss), gptrs, L.ptr(out), L.ptr(st.ws), st.ws.numel(),
+                                           L.stream()), "dh_yolo_loss_dense")
+    return out, grads
+
+
 class _YoloLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, assign, hyp, nc, *p):
@@ -229,7 +299,18 @@ class ComputeLoss:
             self.balance = [x / self.balance[self.ssi] for x in self.balance]
         return loss, rest[0:3]
 
-    def forward_backward(self, p, targets, grad_loss=None, assignment=None):
+    def positives(self, p, targets):
+        """First half of forward_backward, for callers that can start it early: target assignment and the forward of
+        the assigned rows, which read only the targets and the raw maps.  Enqueue it on a side stream beside whatever
+        produces or decodes `p`, make the main stream wait for it (an event), and hand the result to
+        forward_backward(..., positives=...), which then only runs the dense objectness pass and the backward."""
+        if self.sort_obj_iou or self.autobalance:
+            raise NotImplementedError("positives / forward_backward support neither sort_obj_iou nor autobalance")
+        maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
+        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in maps]
+        return _loss_positives(shapes, targets, self.anchors, self.hyp['anchor_t'], self._hyp_struct(), int(self.nc), maps)
+
+    def forward_backward(self, p, targets, grad_loss=None, assignment=None, positives=None):
         """Loss and its gradients in one call, without the autograd engine: (loss[1], loss_items[3], [dL/dp_i]).
 
         The arithmetic of __call__ followed by backward() in five launches instead of nine; grad_loss (1 float on
@@ -244,7 +325,10 @@ class ComputeLoss:
         if grad_loss is None:
             grad_loss = _one(maps[0].device)
         grad_loss = grad_loss.reshape(1).float().contiguous()
-        if assignment is not None:      # an assignment made earlier (possibly on another stream): the separate entries
+        if positives is not None:       # assignment and positives' forward already enqueued (possibly on another stream)
+            out, grads = _loss_dense(positives, int(self.nc), maps, grad_loss)
+            assign = positives.assign
+        elif assignment is not None:    # an assignment made earlier (possibly on another stream): the separate entries
             assign = self._assignment_for(shapes, targets, assignment)
             out, ws = _loss_fwd(assign, hyp, int(self.nc), maps)
             grads = _loss_bwd(assign, hyp, int(self.nc), maps, ws, grad_loss)

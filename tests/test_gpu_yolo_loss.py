@@ -206,3 +206,32 @@ def test_loss_after_decode_reads_compact_logits_bit_exact():
     q = [x.detach().clone().requires_grad_(True) for x in p]
     l3, _ = crit(q, targets)
     assert torch.equal(l2, l3)
+
+
+def test_forward_backward_in_two_halves_matches_the_fused_call():
+    """ComputeLoss.positives on a side stream, then forward_backward(positives=...) on the main one: the same kernels
+    as the single call (float atomics on shared cells and the reduction's grouping may move the last bits)."""
+    from object_detection_amd.yolo import detect_decode
+    from object_detection_amd.yolo_loss import ComputeLoss
+    rs = np.random.RandomState(77)
+    anchors = oy.grid_anchors()
+    levels = [T(x).cuda() for x in synth_head(rs, 8, 320, 80)]
+    targets = T(synth_targets(rs, 90, 8)).cuda()
+    crit = ComputeLoss(FakeModel(anchors.cuda(), 80, dict(oy.HYP_SCRATCH)))
+    l0, i0, g0 = crit.forward_backward(levels, targets)
+    side = torch.cuda.Stream()
+    for decode_between in (False, True):
+        with torch.cuda.stream(side):
+            st = crit.positives(levels, targets)
+            done = torch.cuda.Event()
+            done.record()
+        if decode_between:      # the dense half then reads the objectness logits the decode left behind
+            detect_decode(levels, anchors.cuda(), torch.tensor(oy.YOLOV5S_STRIDES))
+        torch.cuda.current_stream().wait_event(done)
+        l1, i1, g1 = crit.forward_backward(levels, targets, positives=st)
+        close(l1, l0, rtol=1e-6)
+        close(i1, i0, rtol=1e-6)
+        for a, b in zip(g1, g0):
+            close(a, b, rtol=1e-6)
+    with pytest.raises(RuntimeError):
+        crit.forward_backward([x.clone() for x in levels], targets, positives=st)
