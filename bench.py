@@ -216,13 +216,15 @@ def main():
     nms_stream = torch.cuda.Stream() if overlap else main_stream
     loss_stream = torch.cuda.Stream() if n_streams == 3 else main_stream
     early = overlap and not args.autograd and args.early_positives
-    pos_stream = torch.cuda.Stream() if early else None
+    pos_stream = torch.cuda.Stream(priority=int(os.environ.get("DH_BENCH_POS_PRIORITY", "0"))) if early else None
     set_stream = torch.cuda.set_stream
 
     def launch(record, detail=False):
         """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation.
-        record: bracket the decode launch with timing events (every timed step); detail: also the other stages
-        (every 4th timed step: each event is a marker packet in the queue and costs host time, too).
+        record: a timed step; detail: bracket the stages of this step with timing events (every 4th timed step: each
+        event is a marker packet that the next kernel of the stream waits behind -- the kernel trace shows ~5 us per
+        event on the critical stream -- and costs host time, too).  The other steps carry the one event the NMS stream
+        needs to wait for the decode.
         The loss is enqueued before the NMS chain: it continues the critical (main) stream, the NMS chain only has to
         be done by the time its step is finished one iteration later."""
         marks = mark_pool.pop() if record else None
@@ -235,9 +237,9 @@ def main():
             pos_done = torch.cuda.Event()
             pos_done.record()
             set_stream(main_stream)
-        if record: marks[0].record()
+        if detail: marks[0].record()
         z = f_decode()
-        if record: marks[1].record()
+        if detail: marks[1].record()
         h1 = time.perf_counter()
         if overlap:
             decoded = torch.cuda.Event()
@@ -290,17 +292,19 @@ def main():
 
     step_wall = []
 
+    SAMPLE_EVERY = 4      # timed steps between two that carry the stage-timing events
+
     def run(n, record):
         """n steps, software-pipelined: the host half of step i runs while the GPU works on step i+1."""
         all_marks, prev, dets = [], None, None
         for i in range(n):
             if record:
                 step_wall.append(time.perf_counter())
-            job = launch(record, i % 4 == 0)
+            job = launch(record, i % SAMPLE_EVERY == 0)
             if prev is not None:
                 dets = finish(prev)      # prev's tensors are released here, so the allocator reuses its blocks
             prev = job
-            all_marks.append((job["marks"], i % 4 == 0))
+            all_marks.append((job["marks"], i % SAMPLE_EVERY == 0))
         if prev is not None:
             dets = finish(prev)
         return all_marks, dets
@@ -328,7 +332,7 @@ def main():
     gc.enable()
     for marks, detail in all_marks:     # decode and loss are bracketed on the main stream, nms and the copy on the stream they ran on
         for s, (a, b) in zip(stages, ((0, 1), (6, 2), (3, 4), (4, 5))):
-            if detail or s == "decode":
+            if detail:
                 ev[s].append(marks[a].elapsed_time(marks[b]))
     if world > 1:
         tmax = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
