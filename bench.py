@@ -218,6 +218,7 @@ def main():
     early = overlap and not args.autograd and args.early_positives
     pos_stream = torch.cuda.Stream(priority=int(os.environ.get("DH_BENCH_POS_PRIORITY", "0"))) if early else None
     set_stream = torch.cuda.set_stream
+    split = {"prev_stats": None}
 
     def launch(record, detail=False):
         """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation.
@@ -257,9 +258,6 @@ def main():
         if detail: marks[2].record()
         h2 = time.perf_counter()
         if overlap:
-            if world > 1:      # the collective waits for the loss on the side stream: the next decode does not wait for the other ranks
-                reduced_after = torch.cuda.Event()
-                reduced_after.record()
             nms_stream.wait_event(decoded)
             set_stream(nms_stream)
         if detail: marks[3].record()
@@ -268,10 +266,18 @@ def main():
         host_meta, copied = nms_meta_to_host(meta)           # the step's only device-to-host copy (4*bs ints)
         if detail: marks[5].record()
         if world > 1:
-            if overlap:
-                nms_stream.wait_event(reduced_after)                      # the loss wrote stats on the other stream
-            stats = stats.clone() if backend == "nccl" else stats.cpu()   # (host tensor only in the gloo rehearsal)
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)          # [lbox, lobj, lcls, n_pos] over RCCL
+            # The collective runs on the side stream, so the next decode never waits for the other ranks.  With two
+            # streams it reduces the PREVIOUS step's loss statistics: the side stream has just waited for this step's
+            # decode, which follows that loss on the main stream, so no event of its own is needed on the critical
+            # stream (each one costs ~5 us there); one collective per step all the same.
+            mine = split["prev_stats"] if overlap else stats
+            split["prev_stats"] = stats
+            if mine is not None:
+                if overlap:
+                    mine.record_stream(torch.cuda.current_stream())      # made on the main stream, read on this one
+                mine = mine.clone() if backend == "nccl" else mine.cpu()   # (host tensor only in the gloo rehearsal)
+                dist.all_reduce(mine, op=dist.ReduceOp.SUM)               # [lbox, lobj, lcls, n_pos] over RCCL
+                stats = mine
         if overlap:
             set_stream(main_stream)
         h3 = time.perf_counter()
