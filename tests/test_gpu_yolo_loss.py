@@ -124,7 +124,7 @@ def test_compute_loss_bs8_640_vs_oracle():
 
 
 def test_full_size_bs64_640_pipeline_vs_oracle():
-    """BASELINE configuration 2 at full size: bs 64 @ 640 px, 80 classes, 640 targets.
+    """The headline configuration at full size: bs 64 @ 640 px, 80 classes, 640 targets.
     decode (1e-5), assignment (bit-exact), loss + gradients (1e-5), NMS on the oracle's decoded tensor (bit-exact)."""
     from object_detection_amd.general import non_max_suppression
     from object_detection_amd.yolo import detect_decode
