@@ -158,6 +158,9 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    # rehearsal knob for a one-GPU box: run the process group and the per-step collective with a single rank, so that the
+    # RCCL code path itself (init, all_reduce on the side stream, barrier, max over ranks) is exercised
+    dist_on = world > 1 or bool(os.environ.get("DH_BENCH_FORCE_DIST"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the product path has no CPU fallback")
     # rehearsal knobs for a one-GPU box: all ranks on one device and a host-side backend
@@ -167,12 +170,30 @@ def main():
     backend = os.environ.get("DH_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(backend)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner on stdout when its communicator is created: keep stdout for the one JSON line by
+        # pointing file descriptor 1 at stderr until the communicator exists (a first collective forces that)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+                warm = torch.zeros(1, device=device)
+            else:
+                dist.init_process_group(backend)
+                warm = torch.zeros(1)
+            dist.all_reduce(warm)
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from object_detection_amd.yolo import detect_decode
     from object_detection_amd.yolo_loss import ComputeLoss
@@ -265,7 +286,7 @@ def main():
         if detail: marks[4].record()
         host_meta, copied = nms_meta_to_host(meta)           # the step's only device-to-host copy (4*bs ints)
         if detail: marks[5].record()
-        if world > 1:
+        if dist_on:
             # The collective runs on the side stream, so the next decode never waits for the other ranks.  With two
             # streams it reduces the PREVIOUS step's loss statistics: the side stream has just waited for this step's
             # decode, which follows that loss on the main stream, so no event of its own is needed on the critical
@@ -316,7 +337,7 @@ def main():
         return all_marks, dets
 
     def sync_all():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -340,7 +361,7 @@ def main():
         for s, (a, b) in zip(stages, ((0, 1), (6, 2), (3, 4), (4, 5))):
             if detail:
                 ev[s].append(marks[a].elapsed_time(marks[b]))
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -405,7 +426,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
