@@ -78,6 +78,21 @@ int dh_yolo_decode_f16(const void* const* level_ptrs, const int* ny, const int* 
                        const float* anchor_px, const float* strides, float* out, float* obj_plane, float* obj_logit_plane,
                        void* stream);
 
+/* Detect.forward from the outputs of its 1x1 convolutions onward (object_detection/yolov5/models/yolo.py:53-70):
+ * conv_ptrs[l] is the convolution output of level l, (bs, na*no, ny, nx) contiguous; map_ptrs[l] receives
+ * x[i].view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous(), i.e. the (bs, na, ny, nx, no) head map (yolo.py:54);
+ * out / obj_plane / obj_logit_plane receive what dh_yolo_decode writes for those maps (yolo.py:56-70), bit for bit.
+ * One launch reads the convolution outputs once.  out == NULL: layout change only (the training branch; anchor_px and
+ * strides may then be NULL and the planes must be).  map_ptrs == NULL: decoded tensor only.  Needs no <= 256. */
+int dh_yolo_head_maps(const float* const* conv_ptrs, float* const* map_ptrs, const int* ny, const int* nx, int nl, int bs,
+                      int na, int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
+                      float* obj_logit_plane, void* stream);
+/* Backward of that layout change (what autograd does for the permute + contiguous of yolo.py:54, followed by the
+ * contiguous copy the convolution's backward asks for): grad_map_ptrs[l] (bs, na, ny, nx, no) contiguous ->
+ * grad_conv_ptrs[l] (bs, na*no, ny, nx) contiguous. */
+int dh_yolo_head_maps_bwd(const float* const* grad_map_ptrs, float* const* grad_conv_ptrs, const int* ny, const int* nx,
+                          int nl, int bs, int na, int no, void* stream);
+
 /* Batched non_max_suppression (object_detection/yolov5/utils/general.py:647-738) over
  * pred (bs, A, 5+nc) = [x,y,w,h,obj,cls...].  Output rows are [x1,y1,x2,y2,conf,cls] in the
  * reference's order (score descending; equal scores in candidate order).  The rows of all images are

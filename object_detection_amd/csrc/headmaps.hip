@@ -1,0 +1,291 @@
+// YOLOv5 Detect head: the layout change between the 1x1 convolutions and the head maps, fused with the inference decode.
+//
+// Reference: object_detection/yolov5/models/yolo.py:53-54
+//   x[i] = x[i].view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()      (bs, na*no, ny, nx) -> (bs, na, ny, nx, no)
+// followed, in eval mode, by the decode of yolo.py:56-70 (see decode.hip).  In the reference the permuted copy is one
+// strided pass (read + write of every element) and the decode reads it again; here one launch reads the convolution
+// output once and writes both the maps and the decoded tensor (340 B read + 680 B written per anchor instead of
+// 680 + 680).  The backward entry is the inverse layout change for the gradient that flows back into the convolutions.
+//
+// For a fixed (image, anchor) the convolution output is `no` channel rows of ny*nx floats, and the maps hold the same
+// numbers as ny*nx rows of `no` floats: a 2-D transpose whose output span is contiguous.  A workgroup owns S spatial
+// positions of one (image, anchor): every wave loads whole channel rows (lane = position, 256 contiguous bytes per
+// load), writes them into LDS transposed (lane stride = no floats; conflict-free when no is odd, as 85 is) so that LDS
+// holds the tile in output order, and after one barrier the tile is streamed out with 16-byte LDS reads and 16-byte
+// stores; the decode arithmetic sits between that read and the stores and is the arithmetic of k_yolo_decode.
+#include <stdlib.h>
+
+#include "dh_common.h"
+#include "dh_decode.h"
+#include "../../include/dethead.h"
+
+namespace {
+
+struct head_level {
+    const float* conv;   // (bs, na*no, ny, nx): forward input / backward output
+    float* maps;         // (bs, na, ny, nx, no): forward output (may be null) / backward input
+    uint32_t tiles;      // ceil(ny*nx / S)
+    uint32_t blocks;     // na * tiles
+    uint32_t hw;         // ny*nx
+};
+
+struct head_params {
+    decode_level lvl[DH_MAX_LEVELS];   // output geometry and box constants; `src` is not used here
+    head_level h[DH_MAX_LEVELS];
+    int nl;
+    int na;
+    dh_fastdiv no;
+    uint32_t per_image;
+    uint32_t rows_per_image;
+    float* out;           // decoded (bs, A, no), or null: layout change only
+    float* obj_plane;     // as in dh_yolo_decode
+    float* logit_plane;
+};
+
+__device__ __forceinline__ int find_level(const head_params& P, uint32_t& blk)
+{
+    int l = 0;
+#pragma unroll
+    for (int k = 0; k < DH_MAX_LEVELS - 1; ++k) {
+        if (l == k && k + 1 < P.nl && blk >= P.h[k].blocks) { blk -= P.h[k].blocks; l = k + 1; }
+    }
+    return l;
+}
+
+// channel rows of the convolution layout <-> LDS tile in map order (tile[s*no + c]); TO_LDS selects the direction
+template <int S, bool TO_LDS>
+__device__ __forceinline__ void channel_rows(float* tile, float* conv_rows, uint32_t no, uint32_t hw, uint32_t ns)
+{
+    constexpr uint32_t SUB = S / 64;          // 64-position pieces per channel row of the tile
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t items = no * SUB;
+    for (uint32_t it0 = wave; it0 < items; it0 += 4 * 8) {
+        float v[8];
+        if (TO_LDS) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {      // all eight loads are issued before the first LDS write
+                const uint32_t it = it0 + 4 * u;
+                const uint32_t c = it / SUB, s = (it % SUB) * 64 + lane;
+                v[u] = (it < items && s < ns) ? __builtin_nontemporal_load(conv_rows + (size_t)c * hw + s) : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t it = it0 + 4 * u;
+            const uint32_t c = it / SUB, s = (it % SUB) * 64 + lane;
+            if (it < items && s < ns) {
+                if (TO_LDS) tile[s * no + c] = v[u];
+                else __builtin_nontemporal_store(tile[s * no + c], conv_rows + (size_t)c * hw + s);
+            }
+        }
+    }
+}
+
+template <int S, bool VEC>
+__global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
+{
+    extern __shared__ __align__(16) float tile[];
+    const uint32_t b = blockIdx.y;
+    uint32_t blk = blockIdx.x;
+    const int l = find_level(P, blk);
+    const decode_level& L = P.lvl[l];
+    const head_level& H = P.h[l];
+    const uint32_t no = P.no.d, hw = H.hw;
+    const uint32_t a = blk / H.tiles;
+    const uint32_t s0 = (blk - a * H.tiles) * S;
+    const uint32_t ns = min((uint32_t)S, hw - s0);
+    const size_t plane_row = (size_t)(b * P.na + a) * hw + s0;       // first map row of the tile, (bs, na, ny*nx) order
+
+    channel_rows<S, true>(tile, const_cast<float*>(H.conv) + (size_t)(b * P.na + a) * no * hw + s0, no, hw, ns);
+    __syncthreads();
+
+    float* __restrict__ maps = H.maps ? H.maps + plane_row * no : nullptr;
+    float* __restrict__ dec = P.out ? P.out + (size_t)b * P.per_image + L.first + ((size_t)a * hw + s0) * no : nullptr;
+    const size_t plane_at = (size_t)b * P.rows_per_image + L.row_first + (size_t)a * hw + s0;
+    const float stride = L.stride, aw = L.anchor_px[2 * a], ah = L.anchor_px[2 * a + 1];
+    const uint32_t n = ns * no;
+    if (VEC) {
+        for (uint32_t e = threadIdx.x * 4; e < n; e += 1024) {
+            const dh_f4 x = *reinterpret_cast<const dh_f4*>(tile + e);
+            if (maps) __builtin_nontemporal_store(x, reinterpret_cast<dh_f4*>(maps + e));
+            if (!dec) continue;
+            float y[4] = {dh_sigmoid(x.x), dh_sigmoid(x.y), dh_sigmoid(x.z), dh_sigmoid(x.w)};
+            const uint32_t s = dh_div(e, P.no);
+            const uint32_t c0 = e - s * no;
+            if (c0 < 4 || c0 + 3 >= no) {           // the vector touches box channels of row s or of row s + 1 (never both)
+                const bool next = c0 >= 4;
+                const uint32_t cell = s0 + s + (next ? 1u : 0u);
+                const int k0 = next ? (int)(no - c0) : -(int)c0;
+                const uint32_t gy = dh_div(cell, L.nx);
+                const uint32_t gx = cell - gy * L.nx.d;
+                const float fgx = (float)gx, fgy = (float)gy;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = k - k0;
+                    const float sv = y[k];
+                    const float xy = (sv * 2.0f - 0.5f + ((c & 1) ? fgy : fgx)) * stride;     // yolo.py:60,66
+                    const float t = sv * 2.0f;
+                    const float wh = (t * t) * ((c & 1) ? ah : aw);                           // yolo.py:61,67
+                    if (c >= 0 && c < 4) y[k] = c < 2 ? xy : wh;
+                }
+            }
+            if (P.obj_plane) {
+                int k4 = 4 - (int)c0;
+                uint32_t s4 = s;
+                if (k4 < 0) { k4 += (int)no; s4 = s + 1; }
+                if (k4 < 4) {
+                    P.obj_plane[plane_at + s4] = k4 == 0 ? y[0] : (k4 == 1 ? y[1] : (k4 == 2 ? y[2] : y[3]));
+                    if (P.logit_plane) P.logit_plane[plane_at + s4] = k4 == 0 ? x.x : (k4 == 1 ? x.y : (k4 == 2 ? x.z : x.w));
+                }
+            }
+            const dh_f4 o = {y[0], y[1], y[2], y[3]};
+            __builtin_nontemporal_store(o, reinterpret_cast<dh_f4*>(dec + e));
+        }
+    } else {
+        for (uint32_t e = threadIdx.x; e < n; e += 256) {
+            const float x = tile[e];
+            if (maps) maps[e] = x;
+            if (!dec) continue;
+            float y = dh_sigmoid(x);
+            const uint32_t s = dh_div(e, P.no);
+            const uint32_t c = e - s * no;
+            if (c < 4) y = decode_box(L, a * hw + s0 + s, c, y);
+            if (c == 4 && P.obj_plane) {
+                P.obj_plane[plane_at + s] = y;
+                if (P.logit_plane) P.logit_plane[plane_at + s] = x;
+            }
+            dec[e] = y;
+        }
+    }
+}
+
+// gradient w.r.t. the maps (bs, na, ny, nx, no) -> gradient w.r.t. the convolution output (bs, na*no, ny, nx)
+template <int S, bool VEC>
+__global__ void __launch_bounds__(256) k_yolo_head_maps_bwd(const head_params P)
+{
+    extern __shared__ __align__(16) float tile[];
+    const uint32_t b = blockIdx.y;
+    uint32_t blk = blockIdx.x;
+    const int l = find_level(P, blk);
+    const head_level& H = P.h[l];
+    const uint32_t no = P.no.d, hw = H.hw;
+    const uint32_t a = blk / H.tiles;
+    const uint32_t s0 = (blk - a * H.tiles) * S;
+    const uint32_t ns = min((uint32_t)S, hw - s0);
+    const float* __restrict__ g = H.maps + ((size_t)(b * P.na + a) * hw + s0) * no;
+    const uint32_t n = ns * no;
+    if (VEC) {
+        for (uint32_t e = threadIdx.x * 4; e < n; e += 1024)
+            *reinterpret_cast<dh_f4*>(tile + e) = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(g + e));
+    } else {
+        for (uint32_t e = threadIdx.x; e < n; e += 256) tile[e] = g[e];
+    }
+    __syncthreads();
+    channel_rows<S, false>(tile, const_cast<float*>(H.conv) + (size_t)(b * P.na + a) * no * hw + s0, no, hw, ns);
+}
+
+int tile_positions(int no)
+{
+    static const int want = [] {
+        const char* t = getenv("DH_HEAD_TILE");      // tuning knob, read once
+        const int v = t ? atoi(t) : 64;
+        return v == 128 ? 128 : 64;
+    }();
+    if ((size_t)want * no * sizeof(float) <= 65536) return want;
+    return (size_t)64 * no * sizeof(float) <= 65536 ? 64 : 0;
+}
+
+// fills P and the grid width; returns DH_OK or an error code
+int head_setup(head_params& P, const float* const* conv_ptrs, float* const* map_ptrs, const int* ny, const int* nx, int nl,
+               int bs, int na, int no, const float* anchor_px, const float* strides, int S, uint32_t* gx, bool* vec)
+{
+    static const float zeros[DH_MAX_LEVELS * 2 * DH_MAX_ANCHORS] = {};
+    P.nl = nl;
+    P.na = na;
+    P.no = dh_make_fastdiv((uint32_t)no);
+    if (!dh_make_levels(conv_ptrs, ny, nx, nl, na, no, anchor_px ? anchor_px : zeros, strides ? strides : zeros, P.lvl,
+                        &P.per_image, &P.rows_per_image, nullptr))
+        return DH_ERR_ARG;
+    *gx = 0;
+    *vec = true;
+    for (int l = 0; l < nl; ++l) {
+        head_level& H = P.h[l];
+        H.conv = conv_ptrs[l];
+        H.maps = map_ptrs ? map_ptrs[l] : nullptr;
+        H.hw = (uint32_t)(ny[l] * nx[l]);
+        if ((uint64_t)bs * na * H.hw >= (1ull << 32)) return DH_ERR_ARG;     // 32-bit row indices
+        H.tiles = (H.hw + S - 1) / S;
+        H.blocks = (uint32_t)na * H.tiles;
+        *gx += H.blocks;
+        if (reinterpret_cast<uintptr_t>(H.conv) & 3u) return DH_ERR_ALIGN;
+        *vec = *vec && ((uint64_t)H.hw * no) % 4 == 0 && (!H.maps || dh_aligned16(H.maps));
+    }
+    return DH_OK;
+}
+
+}  // namespace
+
+extern "C" int dh_yolo_head_maps(const float* const* conv_ptrs, float* const* map_ptrs, const int* ny, const int* nx, int nl,
+                                 int bs, int na, int no, const float* anchor_px, const float* strides, float* out,
+                                 float* obj_plane, float* obj_logit_plane, void* stream)
+{
+    if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 5 || bs < 0 || bs > 65535) return DH_ERR_ARG;
+    if (!conv_ptrs || !ny || !nx || (!map_ptrs && !out)) return DH_ERR_ARG;
+    if (out && (!anchor_px || !strides)) return DH_ERR_ARG;
+    if ((obj_plane || obj_logit_plane) && !out) return DH_ERR_ARG;
+    if (obj_logit_plane && !obj_plane) return DH_ERR_ARG;
+    for (int l = 0; map_ptrs && l < nl; ++l)
+        if (!map_ptrs[l]) return DH_ERR_ARG;
+    const int S = tile_positions(no);
+    if (!S) return DH_ERR_ARG;
+    if (bs == 0) return DH_OK;
+    head_params P;
+    uint32_t gx = 0;
+    bool vec = false;
+    const int rc = head_setup(P, conv_ptrs, map_ptrs, ny, nx, nl, bs, na, no, anchor_px, strides, S, &gx, &vec);
+    if (rc != DH_OK) return rc;
+    P.out = out;
+    P.obj_plane = obj_plane;
+    P.logit_plane = obj_logit_plane;
+    vec = vec && (!out || dh_aligned16(out)) && no >= 7;
+    const size_t lds = (size_t)S * no * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (S == 128) {
+        if (vec) hipLaunchKernelGGL((k_yolo_head_maps<128, true>), dim3(gx, bs), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((k_yolo_head_maps<128, false>), dim3(gx, bs), dim3(256), lds, st, P);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_yolo_head_maps<64, true>), dim3(gx, bs), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((k_yolo_head_maps<64, false>), dim3(gx, bs), dim3(256), lds, st, P);
+    }
+    return dh_launch_status();
+}
+
+extern "C" int dh_yolo_head_maps_bwd(const float* const* grad_map_ptrs, float* const* grad_conv_ptrs, const int* ny,
+                                     const int* nx, int nl, int bs, int na, int no, void* stream)
+{
+    if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 1 || bs < 0 || bs > 65535) return DH_ERR_ARG;
+    if (!grad_map_ptrs || !grad_conv_ptrs || !ny || !nx) return DH_ERR_ARG;
+    for (int l = 0; l < nl; ++l)
+        if (!grad_map_ptrs[l] || !grad_conv_ptrs[l]) return DH_ERR_ARG;
+    const int S = tile_positions(no);
+    if (!S) return DH_ERR_ARG;
+    if (bs == 0) return DH_OK;
+    head_params P;
+    uint32_t gx = 0;
+    bool vec = false;
+    // head_level.conv is the side with channel rows (here the output), head_level.maps the side in map order (here the input)
+    const int rc = head_setup(P, grad_conv_ptrs, const_cast<float* const*>(grad_map_ptrs), ny, nx, nl, bs, na, no, nullptr,
+                              nullptr, S, &gx, &vec);
+    if (rc != DH_OK) return rc;
+    P.out = P.obj_plane = P.logit_plane = nullptr;
+    const size_t lds = (size_t)S * no * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (S == 128) {
+        if (vec) hipLaunchKernelGGL((k_yolo_head_maps_bwd<128, true>), dim3(gx, bs), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((k_yolo_head_maps_bwd<128, false>), dim3(gx, bs), dim3(256), lds, st, P);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_yolo_head_maps_bwd<64, true>), dim3(gx, bs), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((k_yolo_head_maps_bwd<64, false>), dim3(gx, bs), dim3(256), lds, st, P);
+    }
+    return dh_launch_status();
+}

@@ -95,6 +95,13 @@ def detect_decode(levels, anchors, stride):
         entry = L.lib().dh_yolo_decode_f16 if half else L.lib().dh_yolo_decode     # fp16 maps are widened on load
         L.check(entry(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
                       L.ptr(out), L.ptr(plane), L.ptr(logits), L.c_void_p(made_on)), "dh_yolo_decode")
+    _remember_planes(out, xs, plane, logits, made_on)
+    return out
+
+
+def _remember_planes(out, xs, plane, logits, made_on):
+    """Registers the two compact objectness planes a decode launch wrote: `plane` for the decoded tensor `out`,
+    `logits` for the raw maps `xs` it was computed from."""
     # entries whose tensor has been freed go at once (they pin 8 bytes per anchor); the bound only guards against a
     # caller that keeps every decoded tensor alive
     for registry, dead in ((_OBJ_PLANES, lambda v: v[0]() is None), (_LOGIT_PLANES, lambda v: any(r() is None for r, _, _ in v[0]))):
@@ -104,7 +111,93 @@ def detect_decode(levels, anchors, stride):
             registry.clear()
     _OBJ_PLANES[out.data_ptr()] = (weakref.ref(out), out._version, plane, made_on)
     _LOGIT_PLANES[xs[0].data_ptr()] = ([(weakref.ref(x), x._version, tuple(x.shape)) for x in xs], logits, made_on)
-    return out
+
+
+def _head_geometry(convs, na):
+    bs = int(convs[0].shape[0])
+    if any(c.dim() != 4 or c.shape[0] != bs or c.shape[1] % na for c in convs):
+        raise RuntimeError(f"Detect head: convolution outputs must be (bs, na*no, ny, nx); got {[tuple(c.shape) for c in convs]}")
+    no = int(convs[0].shape[1]) // na
+    if any(c.shape[1] != na * no for c in convs):
+        raise RuntimeError("Detect head: every level must have na*no channels")
+    return bs, no, [int(c.shape[2]) for c in convs], [int(c.shape[3]) for c in convs]
+
+
+def _head_kernel_takes(convs, no):
+    """The layout-change kernel reads fp32 convolution outputs on a ROCm device and holds a 64-position tile of all
+    `no` channels in LDS; anything else keeps the reference's own permute (a torch copy)."""
+    return no <= 256 and no >= 5 and all(c.is_cuda and c.dtype == torch.float32 for c in convs)
+
+
+def _torch_head_maps(convs, na, no):
+    return [c.view(c.shape[0], na, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2).contiguous() for c in convs]
+
+
+class _HeadMaps(torch.autograd.Function):
+    """yolo.py:54 for every level in one launch, with the inverse layout change as its backward."""
+
+    @staticmethod
+    def forward(ctx, na, *convs):
+        convs = [c.contiguous() for c in convs]
+        bs, no, ny, nx = _head_geometry(convs, na)
+        maps = [torch.empty((bs, na, h, w, no), dtype=torch.float32, device=c.device) for c, h, w in zip(convs, ny, nx)]
+        nl = len(convs)
+        with L.device_guard(convs[0].device):
+            L.check(L.lib().dh_yolo_head_maps((L.c_void_p * nl)(*[c.data_ptr() for c in convs]),
+                                              (L.c_void_p * nl)(*[m.data_ptr() for m in maps]), L.int_array(ny), L.int_array(nx),
+                                              nl, bs, na, no, None, None, None, None, None, L.stream()), "dh_yolo_head_maps")
+        ctx.geometry = (na, no, ny, nx, bs)
+        return tuple(maps)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        na, no, ny, nx, bs = ctx.geometry
+        dev = next(g for g in grads if g is not None).device
+        gm = [(g.float().contiguous() if g is not None else torch.zeros((bs, na, h, w, no), dtype=torch.float32, device=dev))
+              for g, h, w in zip(grads, ny, nx)]
+        gc = [torch.empty((bs, na * no, h, w), dtype=torch.float32, device=dev) for h, w in zip(ny, nx)]
+        nl = len(gm)
+        with L.device_guard(dev):
+            L.check(L.lib().dh_yolo_head_maps_bwd((L.c_void_p * nl)(*[g.data_ptr() for g in gm]),
+                                                  (L.c_void_p * nl)(*[g.data_ptr() for g in gc]), L.int_array(ny),
+                                                  L.int_array(nx), nl, bs, na, no, L.stream()), "dh_yolo_head_maps_bwd")
+        return (None,) + tuple(gc)
+
+
+def head_maps(convs, na):
+    """The head maps of every level from the outputs of the 1x1 convolutions (yolo.py:53-54):
+    (bs, na*no, ny, nx) -> (bs, na, ny, nx, no) contiguous; differentiable."""
+    convs = list(convs)
+    _, no, _, _ = _head_geometry(convs, na)
+    if not _head_kernel_takes(convs, no):
+        return _torch_head_maps(convs, na, no)
+    return list(_HeadMaps.apply(na, *convs))
+
+
+def head_maps_decode(convs, na, anchors, stride):
+    """Eval branch of Detect.forward after the convolutions (yolo.py:53-70): returns (decoded (bs, A, no), head maps).
+    One launch reads the convolution outputs once and writes both; the results equal head_maps + detect_decode bit for bit."""
+    convs = [c.detach() for c in convs]
+    bs, no, ny, nx = _head_geometry(convs, na)
+    if not _head_kernel_takes(convs, no):
+        maps = _torch_head_maps(convs, na, no)
+        return detect_decode(maps, anchors, stride), maps
+    convs = [c.contiguous() for c in convs]
+    nl = len(convs)
+    dev = convs[0].device
+    total = sum(na * h * w for h, w in zip(ny, nx))
+    anchor_px, strides = _anchor_pixels(anchors, stride)
+    maps = [torch.empty((bs, na, h, w, no), dtype=torch.float32, device=dev) for h, w in zip(ny, nx)]
+    out = torch.empty((bs, total, no), dtype=torch.float32, device=dev)
+    planes = torch.empty((2, bs, total), dtype=torch.float32, device=dev)
+    with L.device_guard(dev):
+        made_on = L.raw_stream()
+        L.check(L.lib().dh_yolo_head_maps((L.c_void_p * nl)(*[c.data_ptr() for c in convs]),
+                                          (L.c_void_p * nl)(*[m.data_ptr() for m in maps]), L.int_array(ny), L.int_array(nx),
+                                          nl, bs, na, no, anchor_px, strides, L.ptr(out), L.ptr(planes[0]), L.ptr(planes[1]),
+                                          L.c_void_p(made_on)), "dh_yolo_head_maps")
+    _remember_planes(out, maps, planes[0], planes[1], made_on)
+    return out, maps
 
 
 def descale_pred(p, flips, scale, img_size):
@@ -136,7 +229,8 @@ class Detect(nn.Module):
     """Same constructor, buffers and forward contract as yolo.py:33-70.
 
     Training: returns the list of (bs,na,ny,nx,no) maps.  Eval: returns (decoded (bs,A,no), that list).
-    The 1x1 convolutions stay ordinary nn.Conv2d layers; only the decode arithmetic is replaced.
+    The 1x1 convolutions stay ordinary nn.Conv2d layers; what follows them (the layout change of yolo.py:54 and the
+    decode arithmetic) is one launch in eval mode, and a layout-change launch with its own backward in training.
     """
     stride = None
     onnx_dynamic = False
@@ -156,8 +250,8 @@ class Detect(nn.Module):
     def forward(self, x):
         for i in range(self.nl):
             x[i] = self.m[i](x[i])
-            bs, _, ny, nx = x[i].shape
-            x[i] = x[i].view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
-        if self.training:
-            return x
-        return detect_decode(x, self.anchors, self.stride), x
+        if self.training or torch.is_grad_enabled() and any(c.requires_grad for c in x):
+            x[:] = head_maps(x, self.na)
+            return x if self.training else (detect_decode(x, self.anchors, self.stride), x)
+        z, x[:] = head_maps_decode(x, self.na, self.anchors, self.stride)
+        return z, x

@@ -29,6 +29,16 @@ def grid_anchors(anchors_px=YOLOV5S_ANCHORS_PX, strides=YOLOV5S_STRIDES):
     return a / torch.tensor(strides).view(-1, 1, 1)
 
 
+def head_maps(convs, na):
+    """The layout change between the 1x1 convolutions and the head maps (yolo.py:53-54):
+    (bs, na*no, ny, nx) -> view (bs, na, no, ny, nx) -> permute(0, 1, 3, 4, 2) -> contiguous (bs, na, ny, nx, no)."""
+    out = []
+    for c in convs:
+        bs, ch, ny, nx = c.shape
+        out.append(c.view(bs, na, ch // na, ny, nx).permute(0, 1, 3, 4, 2).contiguous())
+    return out
+
+
 def detect_decode(levels, anchors, strides):
     """Inference branch of Detect.forward (yolo.py:56-70), input already (bs,na,ny,nx,no).
 

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Times the Detect head after its convolutions at bs 64 @ 640 px (YOLOv5s, nc 80) on one GPU:
+torch's permute + contiguous (yolo.py:54), that + detect_decode, the fused launch, and the two backward forms.
+
+  python tools/time_head_maps.py [bs]        (DH_HEAD_TILE=128 selects the 128-position tile)
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detection_amd import yolo  # noqa: E402
+
+bs = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+na, no = 3, 85
+dev = torch.device("cuda:0")
+convs = [torch.randn(bs, na * no, n, n, device=dev) for n in (80, 40, 20)]
+anchors = torch.tensor([[10, 13, 16, 30, 33, 23], [30, 61, 62, 45, 59, 119], [116, 90, 156, 198, 373, 326]],
+                       dtype=torch.float32, device=dev).view(3, 3, 2) / torch.tensor([8.0, 16.0, 32.0], device=dev).view(3, 1, 1)
+stride = torch.tensor([8.0, 16.0, 32.0])
+elems = sum(c.numel() for c in convs)
+
+
+def torch_permute():
+    return [c.view(bs, na, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2).contiguous() for c in convs]
+
+
+def timed(fn, reps=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+maps = torch_permute()
+grads = [torch.randn_like(m) for m in maps]
+
+
+def torch_bwd():      # what autograd + the convolution's backward do with a map-order gradient
+    return [g.permute(0, 1, 4, 2, 3).contiguous() for g in grads]
+
+
+def ours_bwd():
+    return yolo._HeadMaps.backward(ctx, *grads)
+
+
+class ctx:
+    geometry = (na, no, [80, 40, 20], [80, 40, 20], bs)
+
+
+rows = [
+    ("torch permute+contiguous (yolo.py:54)", torch_permute, 2 * elems * 4),
+    ("torch permute + detect_decode", lambda: yolo.detect_decode(torch_permute(), anchors, stride), 4 * elems * 4),
+    ("detect_decode alone", lambda: yolo.detect_decode(maps, anchors, stride), 2 * elems * 4),
+    ("head_maps (layout change only)", lambda: yolo.head_maps(convs, na), 2 * elems * 4),
+    ("head_maps_decode (fused)", lambda: yolo.head_maps_decode(convs, na, anchors, stride), 3 * elems * 4),
+    ("torch backward copy", torch_bwd, 2 * elems * 4),
+    ("head_maps backward", ours_bwd, 2 * elems * 4),
+]
+for name, fn, nbytes in rows:
+    ms = timed(fn)
+    print(f"{name:42s} {ms * 1e3:8.1f} us   {nbytes / ms / 1e6:8.1f} GB/s of its own algorithmic bytes", flush=True)
