@@ -135,6 +135,16 @@ int dh_yolo_decode_nms_f16(const void* const* level_ptrs, const int* ny, const i
                            int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* Merge-NMS, the step of non_max_suppression that the reference keeps behind its local switch `merge`
+ * (object_detection/yolov5/utils/general.py:668,725-731), applied to the result of the dh_nms_batched /
+ * dh_yolo_decode_nms call that has just run with k_select = 0 on the same workspace and stream (same bs, nc, cap, max_nms,
+ * max_det): in every image with 1 < n < 3000 candidates each output row's box becomes the score-weighted mean of all
+ * candidate boxes whose IoU with it (object_detection/yolov5/utils/metrics.py:242-264 on the class-shifted boxes) exceeds
+ * iou_thres; with redundant != 0 (general.py:666) rows that matched nothing but themselves are dropped, the image's rows
+ * close up in order and out_span[b] gets the new count.  max_det <= 4096. */
+int dh_nms_merge(float* out, int* out_span, int bs, int nc, int cap, int max_nms, int max_det, double iou_thres, int agnostic,
+                 double max_wh, int redundant, void* workspace, size_t workspace_bytes, void* stream);
+
 /* torchvision.ops.nms(boxes[n,4] xyxy, scores[n], iou_threshold) as called at
  * object_detection/yolov5/utils/general.py:722 and object_detection/detectors/centernet/dataset.py:263:
  * keep_index (n int64, device) receives the kept original indices in score-descending order

@@ -1472,6 +1472,111 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
 
 namespace {
 
+// ------------------------------------------------------------------------------------------ merge-NMS
+// general.py:725-731, a step the reference keeps behind the local switch `merge` (general.py:668).  For an image with
+// 1 < n < 3000 candidates every output row's box becomes the score-weighted mean of all candidate boxes whose IoU with
+// it exceeds the threshold (IoU of metrics.py:242-264 on the class-shifted boxes, weights = scores, the sum runs over the
+// unshifted boxes), and rows that matched no candidate but themselves are dropped (`redundant`, general.py:666,730-731).
+// One workgroup per image; one wave per output row walks the image's candidates (`det`, left in the workspace by the
+// general NMS path in score order).  The rows are rewritten in place and closed up in order.
+#define MERGE_MAX_DET 4096
+__global__ void __launch_bounds__(1024) k_nms_merge(const float* __restrict__ det, int m_cap, const int* __restrict__ counts,
+                                                    const int* __restrict__ m_arr, float off, float thr, int redundant,
+                                                    float* __restrict__ out, int2* __restrict__ out_span)
+{
+    __shared__ unsigned char s_keep[MERGE_MAX_DET];
+    __shared__ int wcount[16];
+    const int b = blockIdx.x;
+    const int n = counts[b], m = m_arr[b];
+    if (!(n > 1 && n < 3000)) return;                              // general.py:725 (n: candidates before any truncation)
+    const int2 span = out_span[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* __restrict__ cand = det + (size_t)b * m_cap * 6;
+    for (int i = wave; i < span.y; i += 16) {
+        float* __restrict__ o = out + ((size_t)span.x + i) * 6;
+        const float shift = o[5] * off;                            // general.py:720
+        const float x1 = o[0] + shift, y1 = o[1] + shift, x2 = o[2] + shift, y2 = o[3] + shift;    // general.py:721
+        const float area = (x2 - x1) * (y2 - y1);
+        float wsum = 0.0f, sx1 = 0.0f, sy1 = 0.0f, sx2 = 0.0f, sy2 = 0.0f;
+        int hits = 0;
+        for (int j = lane; j < m; j += 64) {
+            const float* __restrict__ c = cand + (size_t)j * 6;
+            const float u1 = c[0], v1 = c[1], u2 = c[2], v2 = c[3], score = c[4];
+            const float cs = c[5] * off;
+            const float a1 = u1 + cs, b1 = v1 + cs, a2 = u2 + cs, b2 = v2 + cs;
+            const float carea = (a2 - a1) * (b2 - b1);
+            const float inter = fmaxf(fminf(x2, a2) - fmaxf(x1, a1), 0.0f) * fmaxf(fminf(y2, b2) - fmaxf(y1, b1), 0.0f);
+            const float iou = __fdiv_rn(inter, area + carea - inter);             // metrics.py:264
+            if (iou > thr) {                                                      // general.py:727-728
+                ++hits;
+                wsum += score;
+                sx1 += score * u1; sy1 += score * v1; sx2 += score * u2; sy2 += score * v2;
+            }
+        }
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) {
+            hits += __shfl_xor(hits, k, 64);
+            wsum += __shfl_xor(wsum, k, 64);
+            sx1 += __shfl_xor(sx1, k, 64); sy1 += __shfl_xor(sy1, k, 64);
+            sx2 += __shfl_xor(sx2, k, 64); sy2 += __shfl_xor(sy2, k, 64);
+        }
+        if (lane == 0) {
+            o[0] = __fdiv_rn(sx1, wsum); o[1] = __fdiv_rn(sy1, wsum);             // general.py:729
+            o[2] = __fdiv_rn(sx2, wsum); o[3] = __fdiv_rn(sy2, wsum);
+            s_keep[i] = (!redundant || hits > 1) ? 1 : 0;                         // general.py:730-731
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (!redundant) return;
+    int done = 0;
+    for (int base = 0; base < span.y; base += 1024) {
+        const int i = base + threadIdx.x;
+        const bool k = i < span.y && s_keep[i] != 0;
+        float row[6];
+        if (k) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) row[q] = out[((size_t)span.x + i) * 6 + q];
+        }
+        const u64 bm = __ballot(k);
+        if (lane == 0) wcount[wave] = __popcll(bm);
+        __syncthreads();                      // every row of this chunk has been read before any is overwritten
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int c = wcount[w]; if (w < wave) before += c; all += c; }
+        if (k) {
+            const int pos = done + before + __popcll(bm & lanemask_lt());
+#pragma unroll
+            for (int q = 0; q < 6; ++q) out[((size_t)span.x + pos) * 6 + q] = row[q];
+        }
+        done += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out_span[b] = make_int2(span.x, done);
+}
+
+}  // namespace
+
+extern "C" int dh_nms_merge(float* out, int* out_span, int bs, int nc, int cap, int max_nms, int max_det, double iou_thres,
+                            int agnostic, double max_wh, int redundant, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (bs < 0 || bs > 65535 || nc < 1 || cap < 1 || max_nms < 1 || max_det < 1 || max_det > MERGE_MAX_DET) return DH_ERR_ARG;
+    if (bs == 0) return DH_OK;
+    if (!out || !out_span || !workspace) return DH_ERR_ARG;
+    const nms_layout L = make_layout(bs, cap, max_nms, nc);
+    if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
+    char* ws = (char*)workspace;
+    // box_iou(...) > iou_thres compares fp32 values with the threshold converted to fp32 (torch's type promotion of a
+    // Python scalar against a float tensor), unlike the comparison in double inside the NMS proper
+    hipLaunchKernelGGL(k_nms_merge, dim3(bs), dim3(1024), 0, (hipStream_t)stream, (const float*)(ws + L.off_det), L.m_cap,
+                       (const int*)(ws + L.off_counts), (const int*)(ws + L.off_m), agnostic ? 0.0f : (float)max_wh,
+                       (float)iou_thres, redundant ? 1 : 0, out, (int2*)out_span);
+    return dh_launch_status();
+}
+
+namespace {
+
 int decode_nms_run(const void* const* level_ptrs, bool half, const int* ny, const int* nx, int nl, int bs, int na, int no,
                    const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
                    int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap, int k_select,

@@ -122,7 +122,7 @@ def _with_apriori_labels(pred, labels, nc):
 
 
 def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-               labels=(), max_det=300, cap=None, k_select=None):
+               labels=(), max_det=300, cap=None, k_select=None, merge=False):
     """Enqueue the whole NMS pipeline; nothing is copied to the host (safe inside HIP graph capture).
 
     Returns (rows, meta, cap): rows (bs*max_det, 6) packed detections, meta int32 [bs x {first row, row
@@ -135,6 +135,7 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     k_select = K_SMALL: one workgroup per image does everything after the prefilter (three launches instead of
     seven); images with more than SMALL_MAX candidates are flagged the same way.  k_select = None picks K_SMALL
     when the last call of the same kind stayed below SMALL_BELOW candidates per image, K_SELECT otherwise.
+    merge: merge-NMS (general.py:725-731) on the result; it needs every candidate, so the general path runs (k_select=0).
     """
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
@@ -162,14 +163,22 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
     key = ("nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
-    k_select = _first_attempt(key, max_det, k_select)
+    k_select = 0 if merge else _first_attempt(key, max_det, k_select)
     _remember(rows, key, k_select)
     with L.device_guard(dev):
         L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
                                    int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select),
                                    L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs),
                                    L.c_void_p(meta.data_ptr() + 12 * bs), L.ptr(ws), ws_bytes, L.stream()), "dh_nms_batched")
+        if merge:
+            _merge(lib, rows, meta, bs, nc, cap, max_det, iou_thres, agnostic, ws, ws_bytes)
     return rows, meta, cap
+
+
+def _merge(lib, rows, meta, bs, nc, cap, max_det, iou_thres, agnostic, ws, ws_bytes):
+    """Merge-NMS over the result the NMS call left in rows / meta and the candidates it left in its workspace."""
+    L.check(lib.dh_nms_merge(L.ptr(rows), L.ptr(meta), bs, nc, cap, MAX_NMS, max_det, float(iou_thres), int(bool(agnostic)),
+                             float(MAX_WH), 1, L.ptr(ws), ws_bytes, L.stream()), "dh_nms_merge")
 
 
 def _class_keep(classes, nc, dev):
@@ -183,7 +192,7 @@ def _class_keep(classes, nc, dev):
 
 
 def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                      multi_label=False, max_det=300, cap=None, k_select=None):
+                      multi_label=False, max_det=300, cap=None, k_select=None, merge=False):
     """nms_launch fed by the raw head maps: the same (rows, meta, cap) as
     nms_launch(detect_decode(levels, anchors, stride), ...), without writing or reading the decoded tensor."""
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
@@ -215,7 +224,7 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     ws = L.workspace(ws_bytes, dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
     key = ("detect_nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
-    k_select = _first_attempt(key, max_det, k_select)
+    k_select = 0 if merge else _first_attempt(key, max_det, k_select)
     _remember(rows, key, k_select)
     with L.device_guard(dev):
         entry = lib.dh_yolo_decode_nms_f16 if half else lib.dh_yolo_decode_nms     # fp16 maps are widened on load
@@ -225,18 +234,20 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
                       L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs),
                       L.c_void_p(meta.data_ptr() + 12 * bs), L.ptr(ws), ws_bytes, L.stream()),
                 "dh_yolo_decode_nms")
+        if merge:
+            _merge(lib, rows, meta, bs, nc, cap, max_det, iou_thres, agnostic, ws, ws_bytes)
     return rows, meta, cap
 
 
 def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-               max_det=300):
+               max_det=300, merge=False):
     """non_max_suppression(Detect(x)[0], ...) (val.py:194,203; detect.py:126,132) straight from the raw head maps
     `levels` (list of (bs,na,ny,nx,5+nc)); anchors / stride as Detect holds them.  Bit-identical to the two-call
     sequence, at about half its HBM traffic: the decoded (bs, A, 5+nc) tensor is neither written nor read."""
     cap, k_select = None, None
     while True:
         rows, meta, cap = detect_nms_launch(levels, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
-                                            max_det, cap, k_select)
+                                            max_det, cap, k_select, merge)
         if rows is None:
             return [torch.zeros((0, 6), device=levels[0].device)] * levels[0].shape[0]
         result, need = nms_finish(rows, meta, cap)
@@ -283,8 +294,16 @@ def nms_views(rows, host, cap):
     order = [i for i in sorted(range(bs), key=first.__getitem__) if count[i]]
     result = [torch.zeros((0, 6), device=rows.device)] * bs
     if order:
-        for i, piece in zip(order, rows[:sum(count)].split([count[i] for i in order])):
-            result[i] = piece
+        at, packed = 0, True
+        for i in order:
+            packed = packed and first[i] == at
+            at += count[i]
+        if packed:
+            for i, piece in zip(order, rows[:at].split([count[i] for i in order])):
+                result[i] = piece
+        else:       # merge-NMS dropped rows of some images: each image still starts at its first row
+            for i in order:
+                result[i] = rows[first[i]:first[i] + count[i]]
     return result, cap
 
 
@@ -294,8 +313,11 @@ def nms_finish(rows, meta, cap):
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-                        labels=(), max_det=300):
+                        labels=(), max_det=300, merge=False):
     """Batched NMS on (bs, A, 5+nc) predictions -> list of (k,6) [xyxy, conf, cls] per image (general.py:647-738).
+
+    merge is the one addition to the reference's signature: there the merge-NMS step (general.py:725-731) sits behind a
+    local constant (`merge = False`, general.py:668); the default reproduces that, merge=True runs the step.
 
     The whole batch is processed by one sequence of kernel launches and a single device-to-host copy
     of the per-image counts; the returned tensors are views of one packed buffer.
@@ -304,7 +326,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     cap, k_select = None, None
     while True:
         rows, meta, cap = nms_launch(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det, cap,
-                                     k_select)
+                                     k_select, merge)
         if rows is None:
             return [torch.zeros((0, 6), device=prediction.device)] * prediction.shape[0]
         result, need = nms_finish(rows, meta, cap)

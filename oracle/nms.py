@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 import torch
 
-from .boxes import xywh2xyxy
+from .boxes import box_iou, xywh2xyxy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -79,8 +79,11 @@ def stable_desc_order(scores):
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                        multi_label=False, labels=(), max_det=300, nms_fn=None):
-    """general.py:647-738 -> list of (k,6) tensors [x1,y1,x2,y2,conf,cls] per image."""
+                        multi_label=False, labels=(), max_det=300, nms_fn=None, merge=False):
+    """general.py:647-738 -> list of (k,6) tensors [x1,y1,x2,y2,conf,cls] per image.
+
+    merge: the reference's local switch of general.py:668 (always False there) made a parameter; True runs the
+    merge-NMS step of general.py:725-731 with redundant = True (general.py:666)."""
     nms_fn = nms if nms_fn is None else nms_fn
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
@@ -115,8 +118,14 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         if n > MAX_NMS:                                            # :716-717
             det = det[stable_desc_order(det[:, 4])[:MAX_NMS]]
         shift = det[:, 5:6] * (0 if agnostic else MAX_WH)          # :720
-        keep = nms_fn(det[:, :4] + shift, det[:, 4], iou_thres)    # :721-722
+        shifted, scores = det[:, :4] + shift, det[:, 4]            # :721
+        keep = nms_fn(shifted, scores, iou_thres)                  # :722
         if keep.shape[0] > max_det:                                # :723-724
             keep = keep[:max_det]
+        if merge and (1 < n < 3E3):                                # :725 (n is the count before the max_nms cut)
+            hit = box_iou(shifted[keep], shifted) > iou_thres      # :727
+            weights = hit * scores[None]                           # :728
+            det[keep, :4] = torch.mm(weights, det[:, :4]).float() / weights.sum(1, keepdim=True)   # :729
+            keep = keep[hit.sum(1) > 1]                            # :730-731 (redundant = True, :666)
         results[img] = det[keep]
     return results

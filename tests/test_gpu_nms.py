@@ -10,7 +10,7 @@ import torch
 from oracle import boxes as ob
 from oracle import nms as onms
 from tests._synth import make_big_pred, synth_pred
-from tests.test_oracle_golden import NMS_VARIANTS, nms_labels, unpack
+from tests.test_oracle_golden import MERGE_VARIANTS, NMS_VARIANTS, merge_close, nms_labels, unpack
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +38,39 @@ def test_non_max_suppression_golden(golden, tag):
     got = non_max_suppression(pred, **kw)
     same_lists(got, unpack(g, tag))
     assert torch.equal(pred, before)          # the input is not modified (the reference works on a copy)
+
+
+@pytest.mark.parametrize("tag", list(MERGE_VARIANTS))
+def test_merge_nms_golden(golden, tag):
+    """merge-NMS (general.py:725-731) against the reference run with its local switch set."""
+    from object_detection_amd.general import non_max_suppression
+    g = golden("nms_merge")
+    pred = T(g["pred"]).cuda()
+    merge_close(non_max_suppression(pred, merge=True, **MERGE_VARIANTS[tag]), unpack(g, tag))
+    # the default leaves the step out, as the reference does
+    same_lists(non_max_suppression(pred, **MERGE_VARIANTS[tag]), onms.non_max_suppression(T(g["pred"]).clone(), **MERGE_VARIANTS[tag]))
+
+
+def test_merge_nms_wide_and_fused(golden):
+    from object_detection_amd.general import detect_nms, non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    from oracle import yolo as oy
+    from tests._synth import synth_head
+    g = golden("nms_merge")
+    got = non_max_suppression(T(g["wide_pred"]).cuda(), conf_thres=0.0, iou_thres=0.5, merge=True)
+    merge_close(got, unpack(g, "wide"))            # image 0 has >= 3000 candidates and is left as NMS made it
+    # fused path: same rows as the two calls, and as the oracle on the decoded tensor
+    rs = np.random.RandomState(9)
+    levels = [torch.from_numpy(x).cuda() for x in synth_head(rs, 2, 128, 6)]
+    for x in levels:
+        x[..., 4] += 5.0                           # plenty of candidates per image
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    dec = detect_decode(levels, anchors, stride)
+    two = non_max_suppression(dec, conf_thres=0.3, iou_thres=0.3, merge=True)
+    one = detect_nms(levels, anchors, stride, conf_thres=0.3, iou_thres=0.3, merge=True)
+    same_lists(one, two)
+    merge_close(two, [w.numpy() for w in onms.non_max_suppression(dec.cpu(), conf_thres=0.3, iou_thres=0.3, merge=True)])
+    assert sum(int(d.shape[0]) for d in two) > 0
 
 
 def test_nms_single_class_ties_and_big(golden):

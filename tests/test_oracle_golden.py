@@ -157,6 +157,45 @@ def test_non_max_suppression(golden, tag):
         np.testing.assert_array_equal(d.numpy(), w)
 
 
+MERGE_VARIANTS = {
+    "default": {},
+    "multi": dict(conf_thres=0.2, iou_thres=0.6, multi_label=True),
+    "agnostic": dict(agnostic=True, conf_thres=0.3),
+    "maxdet3": dict(max_det=3),
+    "classes": dict(conf_thres=0.1, classes=[1, 4, 9]),
+    "many": dict(conf_thres=0.001, iou_thres=0.5),
+}
+
+
+def merge_close(got, want):
+    """Counts, scores and classes exactly; the merged boxes are fp32 weighted sums whose order of summation the
+    reference leaves to torch.mm, so they are compared to rtol 1e-5."""
+    assert [int(d.shape[0]) for d in got] == [int(w.shape[0]) for w in want]
+    for d, w in zip(got, want):
+        d = d.cpu().numpy()
+        np.testing.assert_array_equal(d[:, 4:], w[:, 4:])
+        np.testing.assert_allclose(d[:, :4], w[:, :4], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", list(MERGE_VARIANTS))
+def test_merge_nms(golden, tag):
+    """general.py:725-731 run by the reference with its local switch set (tools/make_golden.py)."""
+    g = golden("nms_merge")
+    merge_close(onms.non_max_suppression(T(g["pred"]).clone(), merge=True, **MERGE_VARIANTS[tag]), unpack(g, tag))
+    if tag == "default":        # the step changed something: without it the result differs
+        plain = onms.non_max_suppression(T(g["pred"]).clone())
+        assert [d.shape[0] for d in plain] != [w.shape[0] for w in unpack(g, tag)]
+
+
+def test_merge_nms_skips_images_with_3000_candidates(golden):
+    g = golden("nms_merge")
+    assert g["wide_nms_sizes"][0] >= 3000 > g["wide_nms_sizes"][1] > 1
+    got = onms.non_max_suppression(T(g["wide_pred"]).clone(), conf_thres=0.0, iou_thres=0.5, merge=True)
+    merge_close(got, unpack(g, "wide"))
+    plain = onms.non_max_suppression(T(g["wide_pred"]).clone(), conf_thres=0.0, iou_thres=0.5)
+    np.testing.assert_array_equal(got[0].numpy(), plain[0].numpy())       # image 0 untouched
+
+
 def test_nms_special_inputs(golden):
     g = golden("nms")
     got = onms.non_max_suppression(T(g["nc1_pred"]).clone(), conf_thres=0.1, multi_label=True)

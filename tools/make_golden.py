@@ -444,6 +444,62 @@ def gen_nms(y_general):
     save("nms", **out)
 
 
+def reference_nms_with_merge(y_general):
+    """non_max_suppression of utils/general.py with its local switch `merge = False` (general.py:668) set to True: the
+    function's definition is taken from the reference's own file, that one constant is flipped in the syntax tree, and
+    the result is compiled inside the imported module's namespace (so it calls the module's own box_iou, xywh2xyxy and
+    the recording stand-in for torchvision.ops.nms)."""
+    import ast
+    path = os.path.join(REF, "yolov5", "utils", "general.py")
+    tree = ast.parse(open(path).read(), path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "non_max_suppression"][0]
+    flipped = 0
+    for node in ast.walk(fn):
+        if (isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name)
+                and node.targets[0].id == "merge"):
+            assert isinstance(node.value, ast.Constant) and node.value.value is False
+            node.value = ast.copy_location(ast.Constant(value=True), node.value)
+            flipped += 1
+    assert flipped == 1
+    ns = dict(vars(y_general))
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    return ns["non_max_suppression"]
+
+
+def gen_nms_merge(y_general):
+    """Merge-NMS (general.py:725-731): clustered boxes so that most kept rows have neighbours above the threshold."""
+    nms_merge = reference_nms_with_merge(y_general)
+    rs = np.random.RandomState(71)
+    out = {}
+    nc = 16
+    pred = dedupe_scores(synth_pred(rs, 4, 1200, nc, n_obj=8, jitter=5.0, k_per_obj=14), 0.001)
+    pred[3, :, 4] = 0.0                                 # no candidates
+    pred[2, :, 4] *= 0.2                                # nothing above 0.25 except by accident
+    pred[2, 17, 4], pred[2, 17, 5:] = 0.9, 0.0
+    pred[2, 17, 5 + 3] = 0.8                            # an image with exactly one candidate: n = 1, no merge (1 < n)
+    out["pred"] = pred
+    variants = {
+        "default": {},
+        "multi": dict(conf_thres=0.2, iou_thres=0.6, multi_label=True),
+        "agnostic": dict(agnostic=True, conf_thres=0.3),
+        "maxdet3": dict(max_det=3),
+        "classes": dict(conf_thres=0.1, classes=[1, 4, 9]),
+        "many": dict(conf_thres=0.001, iou_thres=0.5),             # every row a candidate, still n < 3000
+    }
+    for tag, kw in variants.items():
+        NMS_CALLS.clear()
+        pack_list(out, tag, nms_merge(T(pred).clone(), **kw))
+        out[tag + "_nms_sizes"] = np.array([c[0].shape[0] for c in NMS_CALLS])
+    # n >= 3000 in an image: the step is skipped there (general.py:725)
+    wide = dedupe_scores(synth_pred(rs, 2, 4000, 4, n_obj=6, k_per_obj=10), 0.001)
+    wide[1, 2500:, 4] = 0.0                              # image 1 stays below 3000 candidates, image 0 does not
+    out["wide_pred"] = wide
+    NMS_CALLS.clear()
+    pack_list(out, "wide", nms_merge(T(wide).clone(), conf_thres=0.0, iou_thres=0.5))
+    out["wide_nms_sizes"] = np.array([c[0].shape[0] for c in NMS_CALLS])
+    save("nms_merge", **out)
+
+
 def gen_box_utils(y_general):
     rs = np.random.RandomState(79)
     out = {}
@@ -726,7 +782,7 @@ def main():
     only = set(sys.argv[1:])
     if only:                      # e.g. `make_golden.py ap`: regenerate the named fixtures only
         gens = {"ap": lambda: gen_ap(y_metrics), "evalmatch": lambda: gen_evalmatch(y_metrics), "tta": gen_tta,
-                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss)}
+                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss), "nms_merge": lambda: gen_nms_merge(y_general)}
         for k in only:
             gens[k]()
         return
@@ -736,6 +792,7 @@ def main():
     gen_build_targets(y_loss)
     gen_compute_loss(y_loss)
     gen_nms(y_general)
+    gen_nms_merge(y_general)
     gen_centernet(a_loss, c_loss, c_data)
     gen_evalmatch(y_metrics)
     gen_tta()
