@@ -87,11 +87,19 @@ int dh_yolo_decode_f16(const void* const* level_ptrs, const int* ny, const int* 
 int dh_yolo_head_maps(const float* const* conv_ptrs, float* const* map_ptrs, const int* ny, const int* nx, int nl, int bs,
                       int na, int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
                       float* obj_logit_plane, void* stream);
+/* The same for a half-precision head (model.half() of object_detection/yolov5/val.py:115,129): convolution outputs and
+ * maps hold fp16 elements; out and the planes stay fp32 and equal dh_yolo_decode_f16 on those maps. */
+int dh_yolo_head_maps_f16(const void* const* conv_ptrs, void* const* map_ptrs, const int* ny, const int* nx, int nl, int bs,
+                          int na, int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
+                          float* obj_logit_plane, void* stream);
 /* Backward of that layout change (what autograd does for the permute + contiguous of yolo.py:54, followed by the
  * contiguous copy the convolution's backward asks for): grad_map_ptrs[l] (bs, na, ny, nx, no) contiguous ->
  * grad_conv_ptrs[l] (bs, na*no, ny, nx) contiguous. */
 int dh_yolo_head_maps_bwd(const float* const* grad_map_ptrs, float* const* grad_conv_ptrs, const int* ny, const int* nx,
                           int nl, int bs, int na, int no, void* stream);
+/* The same on fp16 gradients (training under autocast keeps the head in half precision). */
+int dh_yolo_head_maps_bwd_f16(const void* const* grad_map_ptrs, void* const* grad_conv_ptrs, const int* ny, const int* nx,
+                              int nl, int bs, int na, int no, void* stream);
 
 /* Batched non_max_suppression (object_detection/yolov5/utils/general.py:647-738) over
  * pred (bs, A, 5+nc) = [x,y,w,h,obj,cls...].  Output rows are [x1,y1,x2,y2,conf,cls] in the

@@ -37,6 +37,9 @@ SIGNATURES = {
     "dh_yolo_head_maps": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "dh_yolo_head_maps_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dh_yolo_head_maps_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dh_yolo_head_maps_bwd_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dh_nms_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dh_nms_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p, c_int, c_int,
                                c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -13,8 +13,9 @@
 // load), writes them into LDS transposed (lane stride = no floats; conflict-free when no is odd, as 85 is) so that LDS
 // holds the tile in output order, and after one barrier the tile is streamed out with 16-byte LDS reads and 16-byte
 // stores; the decode arithmetic sits between that read and the stores and is the arithmetic of k_yolo_decode.
-#include <stdlib.h>
-
+// A half-precision head (model.half(), object_detection/yolov5/val.py:115,129) keeps fp16 convolution outputs and fp16
+// maps: every lane then carries two positions per load (S = 128), the tile is held in fp16, and the decode widens to
+// fp32 exactly as dh_yolo_decode_f16 does.
 #include "dh_common.h"
 #include "dh_decode.h"
 #include "../../include/dethead.h"
@@ -22,8 +23,8 @@
 namespace {
 
 struct head_level {
-    const float* conv;   // (bs, na*no, ny, nx): forward input / backward output
-    float* maps;         // (bs, na, ny, nx, no): forward output (may be null) / backward input
+    const void* conv;    // (bs, na*no, ny, nx): forward input / backward output (fp32 or fp16)
+    void* maps;          // (bs, na, ny, nx, no): forward output (may be null) / backward input (same element type)
     uint32_t tiles;      // ceil(ny*nx / S)
     uint32_t blocks;     // na * tiles
     uint32_t hw;         // ny*nx
@@ -52,39 +53,79 @@ __device__ __forceinline__ int find_level(const head_params& P, uint32_t& blk)
     return l;
 }
 
-// channel rows of the convolution layout <-> LDS tile in map order (tile[s*no + c]); TO_LDS selects the direction
-template <int S, bool TO_LDS>
-__device__ __forceinline__ void channel_rows(float* tile, float* conv_rows, uint32_t no, uint32_t hw, uint32_t ns)
+typedef _Float16 dh_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 dh_h2 __attribute__((ext_vector_type(2)));
+
+template <typename T> struct vec4_of;
+template <> struct vec4_of<float> { typedef dh_f4 type; };
+template <> struct vec4_of<_Float16> { typedef dh_h4 type; };
+
+// A lane moves 4 bytes of a channel row per load or store: one fp32 position or two fp16 positions.
+template <typename T> __device__ __forceinline__ void load_lane(const T* p, T* v);
+template <> __device__ __forceinline__ void load_lane<float>(const float* p, float* v) { v[0] = __builtin_nontemporal_load(p); }
+template <> __device__ __forceinline__ void load_lane<_Float16>(const _Float16* p, _Float16* v)
 {
-    constexpr uint32_t SUB = S / 64;          // 64-position pieces per channel row of the tile
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t items = no * SUB;
-    for (uint32_t it0 = wave; it0 < items; it0 += 4 * 8) {
-        float v[8];
+    const dh_h2 h = __builtin_nontemporal_load(reinterpret_cast<const dh_h2*>(p));
+    v[0] = h.x; v[1] = h.y;
+}
+template <typename T> __device__ __forceinline__ void store_lane(T* p, const T* v);
+template <> __device__ __forceinline__ void store_lane<float>(float* p, const float* v) { __builtin_nontemporal_store(v[0], p); }
+template <> __device__ __forceinline__ void store_lane<_Float16>(_Float16* p, const _Float16* v)
+{
+    const dh_h2 h = {v[0], v[1]};
+    __builtin_nontemporal_store(h, reinterpret_cast<dh_h2*>(p));
+}
+
+// channel rows of the convolution layout <-> LDS tile in map order (tile[s*no + c]); TO_LDS selects the direction.
+// The tile spans S = 64 * EPL positions (EPL = positions per lane).  PACKED: ny*nx is a multiple of EPL, so a lane's
+// positions are in range together and its 4 bytes are aligned; otherwise (fp16 with an odd ny*nx) they move one by one.
+template <typename T, bool TO_LDS, bool PACKED>
+__device__ __forceinline__ void channel_rows(T* tile, T* conv_rows, uint32_t no, uint32_t hw, uint32_t ns)
+{
+    constexpr uint32_t EPL = 4 / sizeof(T);
+    const uint32_t wave = threadIdx.x >> 6, s = (threadIdx.x & 63) * EPL;
+    for (uint32_t c0 = wave; c0 < no; c0 += 4 * 8) {
+        T v[8][EPL];
         if (TO_LDS) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {      // all eight loads are issued before the first LDS write
-                const uint32_t it = it0 + 4 * u;
-                const uint32_t c = it / SUB, s = (it % SUB) * 64 + lane;
-                v[u] = (it < items && s < ns) ? __builtin_nontemporal_load(conv_rows + (size_t)c * hw + s) : 0.0f;
+                const uint32_t c = c0 + 4 * u;
+                T* row = conv_rows + (size_t)c * hw + s;
+                if (PACKED) { if (c < no && s < ns) load_lane<T>(row, v[u]); }
+                else {
+#pragma unroll
+                    for (uint32_t k = 0; k < EPL; ++k) if (c < no && s + k < ns) v[u][k] = row[k];
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const uint32_t it = it0 + 4 * u;
-            const uint32_t c = it / SUB, s = (it % SUB) * 64 + lane;
-            if (it < items && s < ns) {
-                if (TO_LDS) tile[s * no + c] = v[u];
-                else __builtin_nontemporal_store(tile[s * no + c], conv_rows + (size_t)c * hw + s);
+            const uint32_t c = c0 + 4 * u;
+            if (c >= no) continue;
+            T* row = conv_rows + (size_t)c * hw + s;
+            if (TO_LDS) {
+#pragma unroll
+                for (uint32_t k = 0; k < EPL; ++k) if (s + k < ns) tile[(s + k) * no + c] = v[u][k];
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < EPL; ++k) if (s + k < ns) v[u][k] = tile[(s + k) * no + c];
+                if (PACKED) { if (s < ns) store_lane<T>(row, v[u]); }
+                else {
+#pragma unroll
+                    for (uint32_t k = 0; k < EPL; ++k) if (s + k < ns) row[k] = v[u][k];
+                }
             }
         }
     }
 }
 
-template <int S, bool VEC>
+template <typename T, bool VEC, bool PACKED>
 __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
 {
-    extern __shared__ __align__(16) float tile[];
+    constexpr uint32_t S = 64 * (4 / sizeof(T));
+    typedef typename vec4_of<T>::type T4;
+    extern __shared__ __align__(16) unsigned char tile_bytes[];
+    T* tile = reinterpret_cast<T*>(tile_bytes);
     const uint32_t b = blockIdx.y;
     uint32_t blk = blockIdx.x;
     const int l = find_level(P, blk);
@@ -93,22 +134,23 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
     const uint32_t no = P.no.d, hw = H.hw;
     const uint32_t a = blk / H.tiles;
     const uint32_t s0 = (blk - a * H.tiles) * S;
-    const uint32_t ns = min((uint32_t)S, hw - s0);
+    const uint32_t ns = min(S, hw - s0);
     const size_t plane_row = (size_t)(b * P.na + a) * hw + s0;       // first map row of the tile, (bs, na, ny*nx) order
 
-    channel_rows<S, true>(tile, const_cast<float*>(H.conv) + (size_t)(b * P.na + a) * no * hw + s0, no, hw, ns);
+    channel_rows<T, true, PACKED>(tile, const_cast<T*>(static_cast<const T*>(H.conv)) + (size_t)(b * P.na + a) * no * hw + s0, no, hw, ns);
     __syncthreads();
 
-    float* __restrict__ maps = H.maps ? H.maps + plane_row * no : nullptr;
+    T* __restrict__ maps = H.maps ? static_cast<T*>(H.maps) + plane_row * no : nullptr;
     float* __restrict__ dec = P.out ? P.out + (size_t)b * P.per_image + L.first + ((size_t)a * hw + s0) * no : nullptr;
     const size_t plane_at = (size_t)b * P.rows_per_image + L.row_first + (size_t)a * hw + s0;
     const float stride = L.stride, aw = L.anchor_px[2 * a], ah = L.anchor_px[2 * a + 1];
     const uint32_t n = ns * no;
     if (VEC) {
         for (uint32_t e = threadIdx.x * 4; e < n; e += 1024) {
-            const dh_f4 x = *reinterpret_cast<const dh_f4*>(tile + e);
-            if (maps) __builtin_nontemporal_store(x, reinterpret_cast<dh_f4*>(maps + e));
+            const T4 raw = *reinterpret_cast<const T4*>(tile + e);
+            if (maps) __builtin_nontemporal_store(raw, reinterpret_cast<T4*>(maps + e));
             if (!dec) continue;
+            const dh_f4 x = {(float)raw.x, (float)raw.y, (float)raw.z, (float)raw.w};
             float y[4] = {dh_sigmoid(x.x), dh_sigmoid(x.y), dh_sigmoid(x.z), dh_sigmoid(x.w)};
             const uint32_t s = dh_div(e, P.no);
             const uint32_t c0 = e - s * no;
@@ -143,9 +185,10 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
         }
     } else {
         for (uint32_t e = threadIdx.x; e < n; e += 256) {
-            const float x = tile[e];
-            if (maps) maps[e] = x;
+            const T raw = tile[e];
+            if (maps) maps[e] = raw;
             if (!dec) continue;
+            const float x = (float)raw;
             float y = dh_sigmoid(x);
             const uint32_t s = dh_div(e, P.no);
             const uint32_t c = e - s * no;
@@ -160,10 +203,13 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
 }
 
 // gradient w.r.t. the maps (bs, na, ny, nx, no) -> gradient w.r.t. the convolution output (bs, na*no, ny, nx)
-template <int S, bool VEC>
+template <typename T, bool VEC, bool PACKED>
 __global__ void __launch_bounds__(256) k_yolo_head_maps_bwd(const head_params P)
 {
-    extern __shared__ __align__(16) float tile[];
+    constexpr uint32_t S = 64 * (4 / sizeof(T));
+    typedef typename vec4_of<T>::type T4;
+    extern __shared__ __align__(16) unsigned char tile_bytes[];
+    T* tile = reinterpret_cast<T*>(tile_bytes);
     const uint32_t b = blockIdx.y;
     uint32_t blk = blockIdx.x;
     const int l = find_level(P, blk);
@@ -171,43 +217,36 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps_bwd(const head_params P)
     const uint32_t no = P.no.d, hw = H.hw;
     const uint32_t a = blk / H.tiles;
     const uint32_t s0 = (blk - a * H.tiles) * S;
-    const uint32_t ns = min((uint32_t)S, hw - s0);
-    const float* __restrict__ g = H.maps + ((size_t)(b * P.na + a) * hw + s0) * no;
+    const uint32_t ns = min(S, hw - s0);
+    const T* __restrict__ g = static_cast<const T*>(H.maps) + ((size_t)(b * P.na + a) * hw + s0) * no;
     const uint32_t n = ns * no;
     if (VEC) {
         for (uint32_t e = threadIdx.x * 4; e < n; e += 1024)
-            *reinterpret_cast<dh_f4*>(tile + e) = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(g + e));
+            *reinterpret_cast<T4*>(tile + e) = __builtin_nontemporal_load(reinterpret_cast<const T4*>(g + e));
     } else {
         for (uint32_t e = threadIdx.x; e < n; e += 256) tile[e] = g[e];
     }
     __syncthreads();
-    channel_rows<S, false>(tile, const_cast<float*>(H.conv) + (size_t)(b * P.na + a) * no * hw + s0, no, hw, ns);
+    channel_rows<T, false, PACKED>(tile, const_cast<T*>(static_cast<const T*>(H.conv)) + (size_t)(b * P.na + a) * no * hw + s0, no, hw, ns);
 }
 
-int tile_positions(int no)
-{
-    static const int want = [] {
-        const char* t = getenv("DH_HEAD_TILE");      // tuning knob, read once
-        const int v = t ? atoi(t) : 64;
-        return v == 128 ? 128 : 64;
-    }();
-    if ((size_t)want * no * sizeof(float) <= 65536) return want;
-    return (size_t)64 * no * sizeof(float) <= 65536 ? 64 : 0;
-}
-
-// fills P and the grid width; returns DH_OK or an error code
-int head_setup(head_params& P, const float* const* conv_ptrs, float* const* map_ptrs, const int* ny, const int* nx, int nl,
-               int bs, int na, int no, const float* anchor_px, const float* strides, int S, uint32_t* gx, bool* vec)
+// fills P and the grid width; returns DH_OK or an error code.  esize: bytes per element of the convolution outputs / maps
+int head_setup(head_params& P, const void* const* conv_ptrs, void* const* map_ptrs, const int* ny, const int* nx, int nl,
+               int bs, int na, int no, const float* anchor_px, const float* strides, size_t esize, uint32_t* gx, bool* vec,
+               bool* packed)
 {
     static const float zeros[DH_MAX_LEVELS * 2 * DH_MAX_ANCHORS] = {};
+    const uint32_t S = 64 * (uint32_t)(4 / esize);
+    if ((size_t)S * no * esize > 65536) return DH_ERR_ARG;       // the tile has to fit the default LDS allowance
     P.nl = nl;
     P.na = na;
     P.no = dh_make_fastdiv((uint32_t)no);
-    if (!dh_make_levels(conv_ptrs, ny, nx, nl, na, no, anchor_px ? anchor_px : zeros, strides ? strides : zeros, P.lvl,
-                        &P.per_image, &P.rows_per_image, nullptr))
+    if (!dh_make_levels(reinterpret_cast<const float* const*>(conv_ptrs), ny, nx, nl, na, no, anchor_px ? anchor_px : zeros,
+                        strides ? strides : zeros, P.lvl, &P.per_image, &P.rows_per_image, nullptr))
         return DH_ERR_ARG;
     *gx = 0;
     *vec = true;
+    *packed = true;
     for (int l = 0; l < nl; ++l) {
         head_level& H = P.h[l];
         H.conv = conv_ptrs[l];
@@ -218,16 +257,16 @@ int head_setup(head_params& P, const float* const* conv_ptrs, float* const* map_
         H.blocks = (uint32_t)na * H.tiles;
         *gx += H.blocks;
         if (reinterpret_cast<uintptr_t>(H.conv) & 3u) return DH_ERR_ALIGN;
-        *vec = *vec && ((uint64_t)H.hw * no) % 4 == 0 && (!H.maps || dh_aligned16(H.maps));
+        *packed = *packed && H.hw % (4 / esize) == 0;
+        *vec = *vec && ((uint64_t)H.hw * no) % 4 == 0 && (!H.maps || (reinterpret_cast<uintptr_t>(H.maps) & (4 * esize - 1)) == 0);
     }
     return DH_OK;
 }
 
-}  // namespace
-
-extern "C" int dh_yolo_head_maps(const float* const* conv_ptrs, float* const* map_ptrs, const int* ny, const int* nx, int nl,
-                                 int bs, int na, int no, const float* anchor_px, const float* strides, float* out,
-                                 float* obj_plane, float* obj_logit_plane, void* stream)
+template <typename T>
+int head_maps_run(const void* const* conv_ptrs, void* const* map_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
+                  int no, const float* anchor_px, const float* strides, float* out, float* obj_plane, float* obj_logit_plane,
+                  void* stream)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 5 || bs < 0 || bs > 65535) return DH_ERR_ARG;
     if (!conv_ptrs || !ny || !nx || (!map_ptrs && !out)) return DH_ERR_ARG;
@@ -236,56 +275,78 @@ extern "C" int dh_yolo_head_maps(const float* const* conv_ptrs, float* const* ma
     if (obj_logit_plane && !obj_plane) return DH_ERR_ARG;
     for (int l = 0; map_ptrs && l < nl; ++l)
         if (!map_ptrs[l]) return DH_ERR_ARG;
-    const int S = tile_positions(no);
-    if (!S) return DH_ERR_ARG;
-    if (bs == 0) return DH_OK;
     head_params P;
     uint32_t gx = 0;
-    bool vec = false;
-    const int rc = head_setup(P, conv_ptrs, map_ptrs, ny, nx, nl, bs, na, no, anchor_px, strides, S, &gx, &vec);
+    bool vec = false, packed = false;
+    const int rc = head_setup(P, conv_ptrs, map_ptrs, ny, nx, nl, bs, na, no, anchor_px, strides, sizeof(T), &gx, &vec, &packed);
     if (rc != DH_OK) return rc;
+    if (bs == 0) return DH_OK;
     P.out = out;
     P.obj_plane = obj_plane;
     P.logit_plane = obj_logit_plane;
     vec = vec && (!out || dh_aligned16(out)) && no >= 7;
-    const size_t lds = (size_t)S * no * sizeof(float);
+    const size_t lds = (size_t)64 * (4 / sizeof(T)) * no * sizeof(T);
     hipStream_t st = (hipStream_t)stream;
-    if (S == 128) {
-        if (vec) hipLaunchKernelGGL((k_yolo_head_maps<128, true>), dim3(gx, bs), dim3(256), lds, st, P);
-        else hipLaunchKernelGGL((k_yolo_head_maps<128, false>), dim3(gx, bs), dim3(256), lds, st, P);
-    } else {
-        if (vec) hipLaunchKernelGGL((k_yolo_head_maps<64, true>), dim3(gx, bs), dim3(256), lds, st, P);
-        else hipLaunchKernelGGL((k_yolo_head_maps<64, false>), dim3(gx, bs), dim3(256), lds, st, P);
-    }
+    if (vec && packed) hipLaunchKernelGGL((k_yolo_head_maps<T, true, true>), dim3(gx, bs), dim3(256), lds, st, P);
+    else if (vec) hipLaunchKernelGGL((k_yolo_head_maps<T, true, false>), dim3(gx, bs), dim3(256), lds, st, P);
+    else if (packed) hipLaunchKernelGGL((k_yolo_head_maps<T, false, true>), dim3(gx, bs), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((k_yolo_head_maps<T, false, false>), dim3(gx, bs), dim3(256), lds, st, P);
     return dh_launch_status();
 }
 
-extern "C" int dh_yolo_head_maps_bwd(const float* const* grad_map_ptrs, float* const* grad_conv_ptrs, const int* ny,
-                                     const int* nx, int nl, int bs, int na, int no, void* stream)
+template <typename T>
+int head_maps_bwd_run(const void* const* grad_map_ptrs, void* const* grad_conv_ptrs, const int* ny, const int* nx, int nl,
+                      int bs, int na, int no, void* stream)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 1 || bs < 0 || bs > 65535) return DH_ERR_ARG;
     if (!grad_map_ptrs || !grad_conv_ptrs || !ny || !nx) return DH_ERR_ARG;
     for (int l = 0; l < nl; ++l)
         if (!grad_map_ptrs[l] || !grad_conv_ptrs[l]) return DH_ERR_ARG;
-    const int S = tile_positions(no);
-    if (!S) return DH_ERR_ARG;
-    if (bs == 0) return DH_OK;
     head_params P;
     uint32_t gx = 0;
-    bool vec = false;
+    bool vec = false, packed = false;
     // head_level.conv is the side with channel rows (here the output), head_level.maps the side in map order (here the input)
-    const int rc = head_setup(P, grad_conv_ptrs, const_cast<float* const*>(grad_map_ptrs), ny, nx, nl, bs, na, no, nullptr,
-                              nullptr, S, &gx, &vec);
+    const int rc = head_setup(P, const_cast<const void* const*>(grad_conv_ptrs), const_cast<void* const*>(grad_map_ptrs), ny, nx,
+                              nl, bs, na, no, nullptr, nullptr, sizeof(T), &gx, &vec, &packed);
     if (rc != DH_OK) return rc;
+    if (bs == 0) return DH_OK;
     P.out = P.obj_plane = P.logit_plane = nullptr;
-    const size_t lds = (size_t)S * no * sizeof(float);
+    const size_t lds = (size_t)64 * (4 / sizeof(T)) * no * sizeof(T);
     hipStream_t st = (hipStream_t)stream;
-    if (S == 128) {
-        if (vec) hipLaunchKernelGGL((k_yolo_head_maps_bwd<128, true>), dim3(gx, bs), dim3(256), lds, st, P);
-        else hipLaunchKernelGGL((k_yolo_head_maps_bwd<128, false>), dim3(gx, bs), dim3(256), lds, st, P);
-    } else {
-        if (vec) hipLaunchKernelGGL((k_yolo_head_maps_bwd<64, true>), dim3(gx, bs), dim3(256), lds, st, P);
-        else hipLaunchKernelGGL((k_yolo_head_maps_bwd<64, false>), dim3(gx, bs), dim3(256), lds, st, P);
-    }
+    if (vec && packed) hipLaunchKernelGGL((k_yolo_head_maps_bwd<T, true, true>), dim3(gx, bs), dim3(256), lds, st, P);
+    else if (vec) hipLaunchKernelGGL((k_yolo_head_maps_bwd<T, true, false>), dim3(gx, bs), dim3(256), lds, st, P);
+    else if (packed) hipLaunchKernelGGL((k_yolo_head_maps_bwd<T, false, true>), dim3(gx, bs), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((k_yolo_head_maps_bwd<T, false, false>), dim3(gx, bs), dim3(256), lds, st, P);
     return dh_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dh_yolo_head_maps(const float* const* conv_ptrs, float* const* map_ptrs, const int* ny, const int* nx, int nl,
+                                 int bs, int na, int no, const float* anchor_px, const float* strides, float* out,
+                                 float* obj_plane, float* obj_logit_plane, void* stream)
+{
+    return head_maps_run<float>(reinterpret_cast<const void* const*>(conv_ptrs), reinterpret_cast<void* const*>(map_ptrs), ny, nx,
+                                nl, bs, na, no, anchor_px, strides, out, obj_plane, obj_logit_plane, stream);
+}
+
+extern "C" int dh_yolo_head_maps_f16(const void* const* conv_ptrs, void* const* map_ptrs, const int* ny, const int* nx, int nl,
+                                     int bs, int na, int no, const float* anchor_px, const float* strides, float* out,
+                                     float* obj_plane, float* obj_logit_plane, void* stream)
+{
+    return head_maps_run<_Float16>(conv_ptrs, map_ptrs, ny, nx, nl, bs, na, no, anchor_px, strides, out, obj_plane,
+                                   obj_logit_plane, stream);
+}
+
+extern "C" int dh_yolo_head_maps_bwd(const float* const* grad_map_ptrs, float* const* grad_conv_ptrs, const int* ny,
+                                     const int* nx, int nl, int bs, int na, int no, void* stream)
+{
+    return head_maps_bwd_run<float>(reinterpret_cast<const void* const*>(grad_map_ptrs),
+                                    reinterpret_cast<void* const*>(grad_conv_ptrs), ny, nx, nl, bs, na, no, stream);
+}
+
+extern "C" int dh_yolo_head_maps_bwd_f16(const void* const* grad_map_ptrs, void* const* grad_conv_ptrs, const int* ny,
+                                         const int* nx, int nl, int bs, int na, int no, void* stream)
+{
+    return head_maps_bwd_run<_Float16>(grad_map_ptrs, grad_conv_ptrs, ny, nx, nl, bs, na, no, stream);
 }

@@ -124,9 +124,10 @@ def _head_geometry(convs, na):
 
 
 def _head_kernel_takes(convs, no):
-    """The layout-change kernel reads fp32 convolution outputs on a ROCm device and holds a 64-position tile of all
-    `no` channels in LDS; anything else keeps the reference's own permute (a torch copy)."""
-    return no <= 256 and no >= 5 and all(c.is_cuda and c.dtype == torch.float32 for c in convs)
+    """The layout-change kernel reads fp32 or fp16 convolution outputs (one type for all levels) on a ROCm device and
+    holds a tile of all `no` channels in LDS; anything else keeps the reference's own permute (a torch copy)."""
+    return (5 <= no <= 256 and convs[0].dtype in (torch.float32, torch.float16)
+            and all(c.is_cuda and c.dtype == convs[0].dtype for c in convs))
 
 
 def _torch_head_maps(convs, na, no):
@@ -140,25 +141,27 @@ class _HeadMaps(torch.autograd.Function):
     def forward(ctx, na, *convs):
         convs = [c.contiguous() for c in convs]
         bs, no, ny, nx = _head_geometry(convs, na)
-        maps = [torch.empty((bs, na, h, w, no), dtype=torch.float32, device=c.device) for c, h, w in zip(convs, ny, nx)]
+        maps = [torch.empty((bs, na, h, w, no), dtype=c.dtype, device=c.device) for c, h, w in zip(convs, ny, nx)]
         nl = len(convs)
+        entry = L.lib().dh_yolo_head_maps_f16 if convs[0].dtype == torch.float16 else L.lib().dh_yolo_head_maps
         with L.device_guard(convs[0].device):
-            L.check(L.lib().dh_yolo_head_maps((L.c_void_p * nl)(*[c.data_ptr() for c in convs]),
+            L.check(entry((L.c_void_p * nl)(*[c.data_ptr() for c in convs]),
                                               (L.c_void_p * nl)(*[m.data_ptr() for m in maps]), L.int_array(ny), L.int_array(nx),
                                               nl, bs, na, no, None, None, None, None, None, L.stream()), "dh_yolo_head_maps")
-        ctx.geometry = (na, no, ny, nx, bs)
+        ctx.geometry = (na, no, ny, nx, bs, convs[0].dtype)
         return tuple(maps)
 
     @staticmethod
     def backward(ctx, *grads):
-        na, no, ny, nx, bs = ctx.geometry
+        na, no, ny, nx, bs, dtype = ctx.geometry
         dev = next(g for g in grads if g is not None).device
-        gm = [(g.float().contiguous() if g is not None else torch.zeros((bs, na, h, w, no), dtype=torch.float32, device=dev))
+        gm = [(g.to(dtype).contiguous() if g is not None else torch.zeros((bs, na, h, w, no), dtype=dtype, device=dev))
               for g, h, w in zip(grads, ny, nx)]
-        gc = [torch.empty((bs, na * no, h, w), dtype=torch.float32, device=dev) for h, w in zip(ny, nx)]
+        gc = [torch.empty((bs, na * no, h, w), dtype=dtype, device=dev) for h, w in zip(ny, nx)]
         nl = len(gm)
+        entry = L.lib().dh_yolo_head_maps_bwd_f16 if dtype == torch.float16 else L.lib().dh_yolo_head_maps_bwd
         with L.device_guard(dev):
-            L.check(L.lib().dh_yolo_head_maps_bwd((L.c_void_p * nl)(*[g.data_ptr() for g in gm]),
+            L.check(entry((L.c_void_p * nl)(*[g.data_ptr() for g in gm]),
                                                   (L.c_void_p * nl)(*[g.data_ptr() for g in gc]), L.int_array(ny),
                                                   L.int_array(nx), nl, bs, na, no, L.stream()), "dh_yolo_head_maps_bwd")
         return (None,) + tuple(gc)
@@ -176,7 +179,8 @@ def head_maps(convs, na):
 
 def head_maps_decode(convs, na, anchors, stride):
     """Eval branch of Detect.forward after the convolutions (yolo.py:53-70): returns (decoded (bs, A, no), head maps).
-    One launch reads the convolution outputs once and writes both; the results equal head_maps + detect_decode bit for bit."""
+    One launch reads the convolution outputs once and writes both; the results equal head_maps + detect_decode bit for bit.
+    A half-precision head keeps fp16 maps; the decoded tensor is fp32, as detect_decode returns it for fp16 maps."""
     convs = [c.detach() for c in convs]
     bs, no, ny, nx = _head_geometry(convs, na)
     if not _head_kernel_takes(convs, no):
@@ -187,12 +191,13 @@ def head_maps_decode(convs, na, anchors, stride):
     dev = convs[0].device
     total = sum(na * h * w for h, w in zip(ny, nx))
     anchor_px, strides = _anchor_pixels(anchors, stride)
-    maps = [torch.empty((bs, na, h, w, no), dtype=torch.float32, device=dev) for h, w in zip(ny, nx)]
+    maps = [torch.empty((bs, na, h, w, no), dtype=convs[0].dtype, device=dev) for h, w in zip(ny, nx)]
     out = torch.empty((bs, total, no), dtype=torch.float32, device=dev)
     planes = torch.empty((2, bs, total), dtype=torch.float32, device=dev)
+    entry = L.lib().dh_yolo_head_maps_f16 if convs[0].dtype == torch.float16 else L.lib().dh_yolo_head_maps
     with L.device_guard(dev):
         made_on = L.raw_stream()
-        L.check(L.lib().dh_yolo_head_maps((L.c_void_p * nl)(*[c.data_ptr() for c in convs]),
+        L.check(entry((L.c_void_p * nl)(*[c.data_ptr() for c in convs]),
                                           (L.c_void_p * nl)(*[m.data_ptr() for m in maps]), L.int_array(ny), L.int_array(nx),
                                           nl, bs, na, no, anchor_px, strides, L.ptr(out), L.ptr(planes[0]), L.ptr(planes[1]),
                                           L.c_void_p(made_on)), "dh_yolo_head_maps")

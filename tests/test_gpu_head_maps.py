@@ -77,6 +77,35 @@ def test_head_maps_backward_is_the_inverse_layout_change(bs, na, no, shapes):
         assert c.grad.is_contiguous() and torch.equal(c.grad.cpu(), ref.grad)
 
 
+HALF_CASES = [c for c in CASES if c[2] <= 85] + [(2, 3, 85, [(5, 5), (3, 3)])]     # the last: odd ny*nx, positions move one by one
+
+
+@pytest.mark.parametrize("bs,na,no,shapes", HALF_CASES)
+def test_half_precision_head(bs, na, no, shapes):
+    """fp16 convolution outputs (model.half(), val.py:115,129): fp16 maps equal torch's permute bit for bit, the decoded
+    tensor equals detect_decode on those fp16 maps (itself equal to the fp32 decode of the widened maps), and the
+    backward is the inverse layout change on fp16 gradients."""
+    from object_detection_amd import yolo
+    nl = len(shapes)
+    convs = [c.half() for c in _convs(6, bs, na, no, shapes)]
+    anchors = (torch.arange(nl * na * 2, dtype=torch.float32).view(nl, na, 2) * 0.37 + 1.1).cuda()
+    stride = torch.tensor([8.0, 16.0, 32.0][:nl])
+    dec, maps = yolo.head_maps_decode(convs, na, anchors, stride)
+    ref_maps = [c.view(bs, na, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2).contiguous() for c in convs]
+    for m, r in zip(maps, ref_maps):
+        assert m.dtype == torch.float16 and torch.equal(m, r)
+    assert dec.dtype == torch.float32
+    assert torch.equal(dec, yolo.detect_decode(ref_maps, anchors, stride))
+    assert torch.equal(dec, yolo.detect_decode([r.float() for r in ref_maps], anchors, stride))
+    for m, w in zip(yolo.head_maps(convs, na), oy.head_maps([c.cpu() for c in convs], na)):
+        assert torch.equal(m.cpu(), w)
+    leaf = [c.clone().requires_grad_() for c in convs]
+    out = yolo.head_maps(leaf, na)
+    torch.autograd.backward(out, [o.detach() for o in out])
+    for c, l in zip(convs, leaf):
+        assert l.grad.dtype == torch.float16 and torch.equal(l.grad, c)
+
+
 def test_head_maps_backward_with_an_unused_level():
     from object_detection_amd.yolo import head_maps
     convs = [c.requires_grad_() for c in _convs(5, 2, 3, 85, [(8, 8), (4, 4)])]

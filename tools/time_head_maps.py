@@ -52,7 +52,7 @@ def ours_bwd():
 
 
 class ctx:
-    geometry = (na, no, [80, 40, 20], [80, 40, 20], bs)
+    geometry = (na, no, [80, 40, 20], [80, 40, 20], bs, torch.float32)
 
 
 rows = [
@@ -63,6 +63,20 @@ rows = [
     ("head_maps_decode (fused)", lambda: yolo.head_maps_decode(convs, na, anchors, stride), 3 * elems * 4),
     ("torch backward copy", torch_bwd, 2 * elems * 4),
     ("head_maps backward", ours_bwd, 2 * elems * 4),
+]
+h_convs = [c.half() for c in convs]
+h_maps = [m.half() for m in maps]
+
+
+def torch_permute_h():
+    return [c.view(bs, na, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2).contiguous() for c in h_convs]
+
+
+rows += [
+    ("fp16: torch permute + detect_decode", lambda: yolo.detect_decode(torch_permute_h(), anchors, stride), elems * (2 + 2 + 2 + 4)),
+    ("fp16: detect_decode alone", lambda: yolo.detect_decode(h_maps, anchors, stride), elems * (2 + 4)),
+    ("fp16: head_maps (layout change only)", lambda: yolo.head_maps(h_convs, na), elems * 4),
+    ("fp16: head_maps_decode (fused)", lambda: yolo.head_maps_decode(h_convs, na, anchors, stride), elems * (2 + 2 + 4)),
 ]
 for name, fn, nbytes in rows:
     ms = timed(fn)
