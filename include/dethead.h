@@ -143,6 +143,23 @@ int dh_yolo_decode_nms_f16(const void* const* level_ptrs, const int* ny, const i
                            int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* The same fed by the outputs of the head's 1x1 convolutions, conv_ptrs[l] = (bs, na*no, ny, nx) contiguous, i.e. the
+ * tensors Detect.forward holds before the layout change of object_detection/yolov5/models/yolo.py:54: neither the head
+ * maps nor the decoded tensor are written or read.  The candidate search reads the objectness planes (contiguous in this
+ * layout) and the class planes of the waves that hold a candidate; detections are bit-identical to
+ * dh_yolo_head_maps + dh_nms_batched.  For callers that only want detections (detect.py:126-132, val.py:194-203 without
+ * compute_loss). */
+int dh_yolo_conv_nms(const float* const* conv_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                     const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
+                     int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+                     int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int dh_yolo_conv_nms_f16(const void* const* conv_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                         const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
+                         int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+                         int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* Merge-NMS, the step of non_max_suppression that the reference keeps behind its local switch `merge`
  * (object_detection/yolov5/utils/general.py:668,725-731), applied to the result of the dh_nms_batched /
  * dh_yolo_decode_nms call that has just run with k_select = 0 on the same workspace and stream (same bs, nc, cap, max_nms,

@@ -51,6 +51,12 @@ SIGNATURES = {
     "dh_yolo_decode_nms_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
                                        c_double, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_yolo_conv_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
+                                 c_double, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_yolo_conv_nms_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
+                                     c_double, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_nms_plain_workspace": (c_size_t, [c_i64]),
     "dh_nms_plain": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_box_convert": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p]),

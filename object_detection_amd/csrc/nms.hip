@@ -61,6 +61,8 @@ struct nms_source {
     const float* pred;
     decode_level lvl[DH_MAX_LEVELS];
     int nl, no;
+    int conv_na;     // 0: lvl[].src are head maps (bs, na, ny, nx, no); na > 0: they are the outputs of the head's 1x1
+                     // convolutions, (bs, na*no, ny, nx), where channel c of a row sits ny*nx elements after channel c - 1
 };
 
 // The raw maps hold fp32 or fp16 elements (T = float or _Float16; decode_level::src is then a pointer in disguise).
@@ -88,6 +90,7 @@ struct raw_row {
     const T* p;       // first element of the row inside its map
     int l;            // level
     uint32_t local;   // row index inside the level (anchor-major, then gy, gx)
+    uint32_t cs;      // distance between consecutive channels of the row (1 in a head map)
 };
 
 template <typename T>
@@ -100,7 +103,15 @@ __device__ __forceinline__ raw_row<T> raw_row_of(const nms_source& S, int b, int
     raw_row<T> r;
     r.l = l;
     r.local = (uint32_t)row - S.lvl[l].row_first;
+    if (S.conv_na) {      // (bs, na*no, ny, nx): anchor a of the level owns `no` channel planes of ny*nx elements
+        const uint32_t hw = S.lvl[l].plane.d;
+        const uint32_t a = dh_div(r.local, S.lvl[l].plane);
+        r.p = reinterpret_cast<const T*>(S.lvl[l].src) + (size_t)b * S.lvl[l].elems + (size_t)a * S.no * hw + (r.local - a * hw);
+        r.cs = hw;
+        return r;
+    }
     r.p = reinterpret_cast<const T*>(S.lvl[l].src) + (size_t)b * S.lvl[l].elems + (size_t)r.local * S.no;
+    r.cs = 1;
     return r;
 }
 
@@ -380,6 +391,185 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
                 if (base + i < cap) out[base + i] = stage[wave][i];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ 1'' prefilter, convolution layout
+// The candidates straight from the outputs of the head's 1x1 convolutions, (bs, na*no, ny, nx): there the objectness
+// logits of one (image, anchor) are a contiguous plane and so is every class, so nothing has to be decomposed into
+// (row, channel).  A thread owns one position and reads its objectness with a coalesced load.  What follows depends on how
+// many of a wave's 64 positions are candidates:
+//   many (validation thresholds): position-parallel -- every lane walks the class planes of its own position, 16 coalesced
+//         loads in flight per lane, so the whole tensor is streamed once at memory speed;
+//   few (inference thresholds):   class-parallel -- the wave takes its candidates four at a time, lane = class, one
+//         round trip per group instead of a walk over all planes for the sake of one or two lanes.
+// Keys are gathered in LDS per workgroup and reach the image's key list with one atomic per workgroup (a wave whose
+// keys do not fit the stage any more writes them directly).  Same key set as k_nms_prefilter on the decoded tensor:
+// sigmoid and the product obj * cls are the arithmetic of the decode followed by general.py:691.
+#define CONV_CH 16              // class planes in flight per lane on the position-parallel path
+#define CONV_DENSE 12           // candidates in a wave from which that path is taken
+#define CONV_STAGE 4096         // keys a workgroup gathers in LDS
+
+struct conv_blocks {
+    uint32_t blocks[DH_MAX_LEVELS];    // na * ceil(ny*nx / 256) per level
+};
+
+// one key per passing lane: into the workgroup's stage, or straight into the image's list when the stage is full.
+// Called by whole waves.  s_n only ever counts keys that are in the stage: a wave that finds no room takes its
+// reservation back, and while it has not, every other wave sees a count beyond the capacity and goes direct too.
+__device__ __forceinline__ void conv_emit(bool pass, u64 key, u64* stage, int* s_n, u64* __restrict__ out, int* counter, int cap)
+{
+    const u64 pm = __ballot(pass);
+    if (!pm) return;
+    const int cnt = __popcll(pm), lane = threadIdx.x & 63;
+    int first = 0, direct = 0;
+    if (lane == 0) {
+        first = atomicAdd(s_n, cnt);
+        if (first + cnt > CONV_STAGE) {
+            atomicSub(s_n, cnt);
+            first = atomicAdd(counter, cnt);
+            direct = 1;
+        }
+    }
+    first = __shfl(first, 0, 64);
+    direct = __shfl(direct, 0, 64);
+    if (!pass) return;
+    const int at = first + __popcll(pm & lanemask_lt());
+    if (!direct) stage[at] = key;
+    else if (at < cap) out[at] = key;
+}
+
+template <bool MULTI, typename T>
+__global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, const conv_blocks CB, int nc, float conf,
+                                                            const unsigned char* __restrict__ class_keep, int cap,
+                                                            u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
+{
+    __shared__ u64 stage[CONV_STAGE];
+    __shared__ int s_n, s_base;
+    const int b = blockIdx.y;
+    uint32_t blk = blockIdx.x;
+    int l = 0;
+#pragma unroll
+    for (int k = 0; k < DH_MAX_LEVELS - 1; ++k)
+        if (l == k && k + 1 < S.nl && blk >= CB.blocks[k]) { blk -= CB.blocks[k]; l = k + 1; }
+    const decode_level& L = S.lvl[l];
+    const uint32_t hw = L.plane.d;
+    const uint32_t tiles = (hw + 255) / 256;
+    const uint32_t a = blk / tiles;
+    const int lane = threadIdx.x & 63;
+    const uint32_t s_wave = (blk - a * tiles) * 256 + (threadIdx.x & ~63u);     // first position of this wave
+    const uint32_t s = s_wave + lane;
+    // channel c of position q of this (image, anchor) sits at plane0[c * hw + q]
+    const T* __restrict__ plane0 = reinterpret_cast<const T*>(L.src) + (size_t)b * L.elems + (size_t)a * S.no * hw;
+    const uint32_t row_wave = L.row_first + a * hw + s_wave;          // row of the decoded tensor (yolo.py:68,70)
+    u64* __restrict__ out = keys + (size_t)b * cap_pad;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    float obj = 0.0f;
+    if (s < hw) obj = dh_sigmoid(ldf_nt(plane0 + 4 * (size_t)hw + s));
+    const bool cand = s < hw && obj > conf;                           // general.py:656,675
+    u64 todo = __ballot(cand);
+    float best = -INFINITY;
+    int best_c = 0;
+    if (__popcll(todo) >= CONV_DENSE) {
+        // Multi-label: sigmoid(x) * obj > conf needs x > logit(conf / obj), so one compare against a per-position bound
+        // (lowered by far more than the rounding of either side can amount to) rules out almost every class without a
+        // sigmoid; the exact test runs only where some lane of the wave gets past it.
+        float bound = -INFINITY;
+        if (MULTI && cand) {
+            const float q = conf / obj;                               // < 1 for a candidate
+            if (q > 0.0f && 1.0f - q > 1e-3f) bound = __logf(q / (1.0f - q)) - 0.01f;
+        }
+        for (int c0 = 0; c0 < nc; c0 += CONV_CH) {
+            float v[CONV_CH];
+#pragma unroll
+            for (int u = 0; u < CONV_CH; ++u)      // element offsets inside one (image, anchor) stay below 2^31 (checked on the host)
+                v[u] = (cand && c0 + u < nc) ? ldf_nt(plane0 + ((uint32_t)(5 + c0 + u) * hw + s)) : 0.0f;
+#pragma unroll
+            for (int u = 0; u < CONV_CH; ++u) {
+                const int c = c0 + u;
+                if (c >= nc) break;                                   // wave-uniform
+                if (MULTI) {
+                    if (__ballot(cand && v[u] > bound) == 0) continue;
+                    if (class_keep != nullptr && class_keep[c] == 0) continue;                              // general.py:705
+                    const float sc = dh_sigmoid(v[u]) * obj;          // yolo.py:62, general.py:691
+                    conv_emit(cand && sc > conf, ((u64)score_key(sc) << 32) | (uint32_t)((row_wave + lane) * nc + c), stage,
+                              &s_n, out, &counts[b], cap);            // general.py:698
+                } else {
+                    const float sc = dh_sigmoid(v[u]) * obj;
+                    if (cand && sc > best) {                          // general.py:701 (first maximum)
+                        best = sc;
+                        best_c = c;
+                    }
+                }
+            }
+        }
+    } else {
+        while (todo) {
+            int r[4];
+            float o[4];
+            int nr = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (todo) {
+                    r[k] = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    nr = k + 1;
+                } else {
+                    r[k] = r[0];
+                }
+                o[k] = __shfl(obj, r[k], 64);
+            }
+            float bv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int bc[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+            for (int h0 = 0; h0 < nc; h0 += 128) {                    // two chunks of 64 classes per round trip
+                float x[4][2];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = h0 + 64 * h + lane;
+                        x[k][h] = c < nc ? ldf(plane0 + (size_t)(5 + c) * hw + s_wave + r[k]) : 0.0f;
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int c = h0 + 64 * h + lane;
+                    if (h0 + 64 * h >= nc) break;                     // wave-uniform
+                    const bool keepc = c < nc && (class_keep == nullptr || class_keep[c] != 0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float sc = dh_sigmoid(x[k][h]) * o[k];  // yolo.py:62, general.py:691
+                        if (MULTI) {
+                            conv_emit(k < nr && keepc && sc > conf,
+                                      ((u64)score_key(sc) << 32) | (uint32_t)((row_wave + r[k]) * nc + c), stage, &s_n, out,
+                                      &counts[b], cap);
+                        } else if (c < nc && sc > bv[k]) {
+                            bv[k] = sc;
+                            bc[k] = c;
+                        }
+                    }
+                }
+            }
+            if (!MULTI) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const row_best rb = wave_argmax_first(bv[k], bc[k]);      // general.py:701 (first maximum)
+                    if (k < nr && lane == r[k]) { best = rb.v; best_c = rb.c; }
+                }
+            }
+        }
+    }
+    if (!MULTI) {
+        const bool pass = cand && best > conf && (class_keep == nullptr || class_keep[best_c] != 0);   // general.py:702,705
+        conv_emit(pass, ((u64)score_key(best) << 32) | (uint32_t)((row_wave + lane) * nc + best_c), stage, &s_n, out, &counts[b],
+                  cap);
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;                                               // workgroup-uniform
+    if (threadIdx.x == 0) s_base = atomicAdd(&counts[b], n);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (s_base + i < cap) out[s_base + i] = stage[i];
 }
 
 // ------------------------------------------------------------------------------------------ 1' prefilter, streaming
@@ -775,10 +965,10 @@ __global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, d
         if (RAW) {
             const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
             const decode_level& L = S.lvl[rr.l];
-            x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p + 0)));
-            y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + 1)));
-            w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2)));
-            h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3)));
+            x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
+            y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
+            w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
+            h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
         } else {
             const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
             x = p[0]; y = p[1]; w = p[2]; h = p[3];
@@ -1069,10 +1259,10 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
         if (RAW) {
             const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
             const decode_level& L = S.lvl[rr.l];
-            x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p + 0)));
-            y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + 1)));
-            w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2)));
-            h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3)));
+            x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
+            y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
+            w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
+            h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
         } else {
             const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
             x = p[0]; y = p[1]; w = p[2]; h = p[3];
@@ -1363,7 +1553,20 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     // compact objectness plane to scan, so the maps are streamed once instead of being visited row by row (measured
     // 163 against 278 us at bs 64).  With a decoded tensor and its plane the row-by-row kernel stays ahead.
     bool streamed = false;
-    if (raw && multi_label && conf_thres < 0.05 && nc + 5 >= 7) {
+    if (S.conv_na) {          // convolution layout: its own candidate search, everything after it is shared
+        conv_blocks CB;
+        uint32_t cgx = 0;
+        for (int l = 0; l < S.nl; ++l) {
+            CB.blocks[l] = (uint32_t)S.conv_na * ((S.lvl[l].plane.d + 255) / 256);
+            cgx += CB.blocks[l];
+        }
+#define DH_CONV(M, T) hipLaunchKernelGGL((k_nms_prefilter_conv<M, T>), dim3(cgx, bs), dim3(256), 0, st, S, CB, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
+        if (half) { if (multi_label) DH_CONV(true, _Float16); else DH_CONV(false, _Float16); }
+        else { if (multi_label) DH_CONV(true, float); else DH_CONV(false, float); }
+#undef DH_CONV
+        streamed = true;
+    }
+    if (!streamed && raw && multi_label && conf_thres < 0.05 && nc + 5 >= 7) {
         stream_params SP;
         SP.no = dh_make_fastdiv((uint32_t)(nc + 5));
         bool ok = true;
@@ -1466,6 +1669,7 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
     S.pred = pred;
     S.nl = 0;
     S.no = nc + 5;
+    S.conv_na = 0;
     return nms_run(S, false, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
                    max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
@@ -1577,7 +1781,7 @@ extern "C" int dh_nms_merge(float* out, int* out_span, int bs, int nc, int cap, 
 
 namespace {
 
-int decode_nms_run(const void* const* level_ptrs, bool half, const int* ny, const int* nx, int nl, int bs, int na, int no,
+int decode_nms_run(const void* const* level_ptrs, bool half, bool conv, const int* ny, const int* nx, int nl, int bs, int na, int no,
                    const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
                    int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap, int k_select,
                    float* out, int* out_span, int* cand_count, int* needs_full, void* workspace, size_t workspace_bytes,
@@ -1589,6 +1793,7 @@ int decode_nms_run(const void* const* level_ptrs, bool half, const int* ny, cons
     S.pred = nullptr;
     S.nl = nl;
     S.no = no;
+    S.conv_na = conv ? na : 0;
     uint32_t per_image = 0, rows = 0;
     if (!dh_make_levels(reinterpret_cast<const float* const*>(level_ptrs), ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image,
                         &rows, nullptr))
@@ -1607,7 +1812,7 @@ extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny,
                                   double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
                                   int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
-    return decode_nms_run(reinterpret_cast<const void* const*>(level_ptrs), false, ny, nx, nl, bs, na, no, anchor_px, strides,
+    return decode_nms_run(reinterpret_cast<const void* const*>(level_ptrs), false, false, ny, nx, nl, bs, na, no, anchor_px, strides,
                           conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out,
                           out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
@@ -1618,9 +1823,31 @@ extern "C" int dh_yolo_decode_nms_f16(const void* const* level_ptrs, const int* 
                                       double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
                                       int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
-    return decode_nms_run(level_ptrs, true, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label, agnostic,
+    return decode_nms_run(level_ptrs, true, false, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label, agnostic,
                           class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace,
                           workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_conv_nms(const float* const* conv_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                                const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
+                                int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
+                                double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return decode_nms_run(reinterpret_cast<const void* const*>(conv_ptrs), false, true, ny, nx, nl, bs, na, no, anchor_px, strides,
+                          conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out,
+                          out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_conv_nms_f16(const void* const* conv_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                                    const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
+                                    int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
+                                    double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                    int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return decode_nms_run(conv_ptrs, true, true, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label,
+                          agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full,
+                          workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t dh_group_nms_workspace(int n_img, int max_rows, int nc)

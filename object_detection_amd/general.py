@@ -192,22 +192,30 @@ def _class_keep(classes, nc, dev):
 
 
 def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                      multi_label=False, max_det=300, cap=None, k_select=None, merge=False):
+                      multi_label=False, max_det=300, cap=None, k_select=None, merge=False, conv_na=None):
     """nms_launch fed by the raw head maps: the same (rows, meta, cap) as
-    nms_launch(detect_decode(levels, anchors, stride), ...), without writing or reading the decoded tensor."""
+    nms_launch(detect_decode(levels, anchors, stride), ...), without writing or reading the decoded tensor.
+    conv_na = na: `levels` are the outputs of the head's convolutions, (bs, na*no, ny, nx), instead of the maps."""
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
     xs, half = L.head_maps(levels)
     nl = len(xs)
-    bs, na, _, _, no = xs[0].shape
-    for x in xs:
-        if x.dim() != 5 or x.shape[0] != bs or x.shape[1] != na or x.shape[4] != no:
-            raise RuntimeError(f"detect_nms: inconsistent level shape {tuple(x.shape)}")
+    if conv_na:
+        na, bs = int(conv_na), xs[0].shape[0]
+        no = xs[0].shape[1] // na
+        for x in xs:
+            if x.dim() != 4 or x.shape[0] != bs or x.shape[1] != na * no:
+                raise RuntimeError(f"conv_nms: convolution outputs must be (bs, na*no, ny, nx), got {tuple(x.shape)}")
+    else:
+        bs, na, _, _, no = xs[0].shape
+        for x in xs:
+            if x.dim() != 5 or x.shape[0] != bs or x.shape[1] != na or x.shape[4] != no:
+                raise RuntimeError(f"detect_nms: inconsistent level shape {tuple(x.shape)}")
     if no < 6:
         raise RuntimeError(f"detect_nms: maps must have 5+nc channels with nc >= 1, got {no}")
     nc = no - 5
-    ny = [int(x.shape[2]) for x in xs]
-    nx = [int(x.shape[3]) for x in xs]
+    ny = [int(x.shape[-3 if not conv_na else 2]) for x in xs]
+    nx = [int(x.shape[-2 if not conv_na else 3]) for x in xs]
     A = sum(na * a * b for a, b in zip(ny, nx))
     dev = xs[0].device
     max_det = int(max_det)
@@ -223,11 +231,14 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
-    key = ("detect_nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
+    key = ("conv_nms" if conv_na else "detect_nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
     k_select = 0 if merge else _first_attempt(key, max_det, k_select)
     _remember(rows, key, k_select)
     with L.device_guard(dev):
-        entry = lib.dh_yolo_decode_nms_f16 if half else lib.dh_yolo_decode_nms     # fp16 maps are widened on load
+        if conv_na:
+            entry = lib.dh_yolo_conv_nms_f16 if half else lib.dh_yolo_conv_nms
+        else:
+            entry = lib.dh_yolo_decode_nms_f16 if half else lib.dh_yolo_decode_nms     # fp16 maps are widened on load
         L.check(entry(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
                       float(conf_thres), float(iou_thres), int(multi_label), int(bool(agnostic)),
                       L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select), L.ptr(rows),
@@ -250,6 +261,27 @@ def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes
                                             max_det, cap, k_select, merge)
         if rows is None:
             return [torch.zeros((0, 6), device=levels[0].device)] * levels[0].shape[0]
+        result, need = nms_finish(rows, meta, cap)
+        if result is not None:
+            return result
+        if need < 0:
+            k_select = _next_attempt(rows)
+        else:
+            cap = need
+
+
+def conv_nms(convs, na, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+             max_det=300, merge=False):
+    """non_max_suppression(Detect(x)[0], ...) (detect.py:126,132; val.py:194,203 without compute_loss) straight from the
+    outputs of Detect's 1x1 convolutions, `convs` = list of (bs, na*no, ny, nx): what Detect.forward holds before the
+    layout change of yolo.py:54.  Neither the head maps nor the decoded tensor are written or read; the detections are
+    bit-identical to non_max_suppression(head_maps_decode(convs, ...)[0], ...)."""
+    cap, k_select = None, None
+    while True:
+        rows, meta, cap = detect_nms_launch(convs, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
+                                            max_det, cap, k_select, merge, conv_na=na)
+        if rows is None:
+            return [torch.zeros((0, 6), device=convs[0].device)] * convs[0].shape[0]
         result, need = nms_finish(rows, meta, cap)
         if result is not None:
             return result

@@ -1,0 +1,91 @@
+"""GPU parity of conv_nms: detections straight from the outputs of Detect's 1x1 convolutions (the tensors
+Detect.forward holds before yolo.py:54) must equal, bit for bit, non_max_suppression on the decoded tensor of the same
+head — which other tests tie to the oracle and the reference's fixtures — and the oracle's own result on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms as onms
+from oracle import yolo as oy
+from tests._synth import synth_head
+
+pytestmark = pytest.mark.gpu
+
+
+def _head(seed, bs, img, nc, boost=3.0, frac=0.02):
+    """Convolution outputs (bs, 3*no, ny, nx) with the bias statistics of yolo.py:196-204 and a share of cells whose
+    objectness and one class are raised, so that every threshold finds candidates and clusters overlap."""
+    rs = np.random.RandomState(seed)
+    convs = []
+    for m in synth_head(rs, bs, img, nc):
+        hot = rs.rand(*m.shape[:4]) < frac
+        m[..., 4] += hot * (boost + 4.0)
+        cls = rs.randint(0, nc, m.shape[:4])
+        np.put_along_axis(m[..., 5:], cls[..., None], np.take_along_axis(m[..., 5:], cls[..., None], -1) + hot[..., None] * (boost + 5.0), -1)
+        m[..., 2:4] *= 0.3                                     # moderate box sizes
+        b, na, ny, nx, no = m.shape
+        convs.append(torch.from_numpy(np.ascontiguousarray(m.transpose(0, 1, 4, 2, 3).reshape(b, na * no, ny, nx))).cuda())
+    return convs
+
+
+VARIANTS = {
+    "default": {},
+    "val": dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+    "multi_c25": dict(conf_thres=0.25, multi_label=True),
+    "agnostic": dict(agnostic=True),
+    "classes": dict(conf_thres=0.05, classes=[0, 2, 5]),
+    "classes_multi": dict(conf_thres=0.05, classes=[0, 2, 5], multi_label=True),
+    "maxdet5": dict(max_det=5),
+    "merge": dict(merge=True, iou_thres=0.3),
+    "conf1": dict(conf_thres=1.0),
+}
+
+
+def same(got, want):
+    assert [int(g.shape[0]) for g in got] == [int(w.shape[0]) for w in want]
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+@pytest.mark.parametrize("shape", [(3, 96, 7), (2, 160, 80)])
+def test_conv_nms_equals_nms_of_the_decoded_head(tag, shape):
+    from object_detection_amd.general import conv_nms, detect_nms, non_max_suppression
+    from object_detection_amd.yolo import head_maps_decode
+    bs, img, nc = shape
+    convs = _head(1, bs, img, nc)
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    kw = VARIANTS[tag]
+    dec, maps = head_maps_decode(convs, 3, anchors, stride)
+    want = non_max_suppression(dec, **kw)
+    got = conv_nms(convs, 3, anchors, stride, **kw)
+    same(got, want)
+    same(detect_nms(maps, anchors, stride, **kw), want)
+    if tag in ("default", "val"):
+        assert sum(int(g.shape[0]) for g in got) > 0
+        ref = onms.non_max_suppression(oy.detect_decode(oy.head_maps([c.cpu() for c in convs], 3), anchors.cpu(), oy.YOLOV5S_STRIDES), **kw)
+        assert [int(g.shape[0]) for g in got] == [int(r.shape[0]) for r in ref]
+        for g, r in zip(got, ref):
+            torch.testing.assert_close(g.cpu(), r, rtol=1e-5, atol=1e-4)      # sigmoid: hardware exp on the device
+
+
+def test_conv_nms_half_precision_head():
+    from object_detection_amd.general import conv_nms
+    convs = [c.half() for c in _head(2, 2, 128, 20)]
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    for kw in (dict(), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)):
+        same(conv_nms(convs, 3, anchors, stride, **kw), conv_nms([c.float() for c in convs], 3, anchors, stride, **kw))
+
+
+def test_conv_nms_full_size_both_modes():
+    """bs 64 @ 640 px: inference thresholds (small path) and validation thresholds (capacity growth, prefix selection)."""
+    from object_detection_amd.general import conv_nms, non_max_suppression
+    from object_detection_amd.yolo import head_maps_decode
+    convs = _head(3, 64, 640, 80, frac=0.002)
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    dec, _ = head_maps_decode(convs, 3, anchors, stride)
+    for kw in (dict(), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)):
+        want = non_max_suppression(dec, **kw)
+        same(conv_nms(convs, 3, anchors, stride, **kw), want)
+        same(conv_nms(convs, 3, anchors, stride, **kw), want)          # second call: the attempt chosen from the first
+        assert sum(int(w.shape[0]) for w in want) > 64
