@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
 // sigmoid and the product obj * cls are the arithmetic of the decode followed by general.py:691.
 #define CONV_CH 16              // class planes in flight per lane on the position-parallel path
 #define CONV_DENSE 12           // candidates in a wave from which that path is taken
-#define CONV_STAGE 4096         // keys a workgroup gathers in LDS
+#define CONV_STAGE 2048         // keys a workgroup gathers in LDS
 
 struct conv_blocks {
     uint32_t blocks[DH_MAX_LEVELS];    // na * ceil(ny*nx / 256) per level
