@@ -106,6 +106,26 @@ def test_half_precision_head(bs, na, no, shapes):
         assert l.grad.dtype == torch.float16 and torch.equal(l.grad, c)
 
 
+def test_device_tensors_never_take_the_torch_copy(monkeypatch):
+    """On a ROCm device fp32 / fp16 convolution outputs always go through the kernels; torch's permute copy is kept only
+    for what the reference also runs elsewhere (Model.__init__ sends a CPU tensor through Detect to derive the strides,
+    yolo.py:107-113)."""
+    from object_detection_amd import yolo
+
+    def boom(*a, **k):
+        raise AssertionError("torch permute copy used for device tensors")
+    monkeypatch.setattr(yolo, "_torch_head_maps", boom)
+    for dtype in (torch.float32, torch.float16):
+        convs = [c.to(dtype) for c in _convs(8, 2, 3, 85, [(8, 8), (4, 4), (2, 2)])]
+        yolo.head_maps(convs, 3)
+        yolo.head_maps_decode(convs, 3, oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES))
+    monkeypatch.undo()
+    cpu = [c.cpu() for c in _convs(8, 1, 3, 85, [(4, 4)])]
+    assert torch.equal(yolo.head_maps(cpu, 3)[0], oy.head_maps(cpu, 3)[0])          # the training branch on the CPU
+    with pytest.raises(RuntimeError):                                              # the decode has no CPU path
+        yolo.head_maps_decode(cpu, 3, oy.grid_anchors()[:1], torch.tensor([8.0]))
+
+
 def test_head_maps_backward_with_an_unused_level():
     from object_detection_amd.yolo import head_maps
     convs = [c.requires_grad_() for c in _convs(5, 2, 3, 85, [(8, 8), (4, 4)])]
