@@ -176,3 +176,38 @@ def test_compute_loss_fuzz(seed):
     close(fi, gi, rtol=1e-6)
     for a, b in zip(fg, gg):
         close(a, b, rtol=1e-6)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_head_fuzz(seed):
+    """Random head geometries (levels, anchors per cell, classes, odd grid sizes, fp32 / fp16): the three routes from the
+    convolution outputs to detections agree bit for bit — conv_nms, detect_nms on the head maps, non_max_suppression on
+    the decoded tensor — and the maps equal torch's permute."""
+    from object_detection_amd.general import conv_nms, detect_nms, non_max_suppression
+    from object_detection_amd.yolo import head_maps_decode
+    rs = np.random.RandomState(9100 + seed)
+    nl, na = int(rs.choice([1, 2, 3, 4])), int(rs.choice([1, 2, 3, 5]))
+    nc = int(rs.choice([1, 2, 7, 80, 130]))
+    bs = int(rs.randint(1, 4))
+    no = nc + 5
+    shapes = [(int(rs.randint(1, 40)), int(rs.randint(1, 40))) for _ in range(nl)]
+    half = bool(rs.rand() < 0.3)
+    convs = []
+    for ny, nx in shapes:
+        x = rs.normal(0, 1.5, (bs, na, no, ny, nx)).astype(np.float32)
+        x[:, :, 4] += rs.choice([-4.0, -1.0, 2.0])                      # sparse, mixed or dense candidates
+        x[:, :, 2:4] *= 0.3
+        c = torch.from_numpy(x.reshape(bs, na * no, ny, nx)).cuda()
+        convs.append(c.half() if half else c)
+    anchors = torch.from_numpy(np.exp(rs.uniform(np.log(0.5), np.log(8), (nl, na, 2))).astype(np.float32)).cuda()
+    stride = torch.tensor([8.0, 16.0, 32.0, 64.0][:nl])
+    kw = dict(conf_thres=float(rs.choice([0.001, 0.05, 0.25, 0.5])), iou_thres=float(rs.choice([0.3, 0.45, 0.6])),
+              agnostic=bool(rs.rand() < 0.3), multi_label=bool(rs.rand() < 0.5), max_det=int(rs.choice([1, 5, 300])))
+    if rs.rand() < 0.3:
+        kw["classes"] = sorted(set(int(c) for c in rs.randint(0, nc, 3)))
+    dec, maps = head_maps_decode(convs, na, anchors, stride)
+    for m, c in zip(maps, convs):
+        assert torch.equal(m, c.view(bs, na, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2).contiguous())
+    want = non_max_suppression(dec, **kw)
+    same_lists(conv_nms(convs, na, anchors, stride, **kw), want)
+    same_lists(detect_nms(maps, anchors, stride, **kw), want)
