@@ -108,3 +108,26 @@ def test_detect_module_detections_equal_forward_plus_nms():
         got = det.detections([f.clone() for f in feats], **kw)
         same(got, want)
         assert sum(int(w.shape[0]) for w in want) > 0
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_conv_nms_when_every_class_of_every_position_passes(half):
+    """A workgroup finds far more keys (positions x classes) than its LDS stage holds, so most waves write their keys
+    straight into the image's list, and the list itself outgrows the first capacity (the call is repeated)."""
+    from object_detection_amd.general import conv_nms, non_max_suppression
+    from object_detection_amd.yolo import head_maps_decode
+    rs = np.random.RandomState(12)
+    bs, nc = 2, 80
+    convs = []
+    for n in (16, 8, 4):
+        x = rs.normal(0, 1.0, (bs, 3, nc + 5, n, n)).astype(np.float32)
+        x[:, :, 4:] += 4.0                                   # objectness and every class near 1
+        x[:, :, 2:4] *= 0.2
+        c = torch.from_numpy(x.reshape(bs, 3 * (nc + 5), n, n)).cuda()
+        convs.append(c.half() if half else c)
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    dec, _ = head_maps_decode(convs, 3, anchors, stride)
+    want = non_max_suppression(dec, **kw)
+    same(conv_nms(convs, 3, anchors, stride, **kw), want)
+    assert all(int(w.shape[0]) == 300 for w in want)
