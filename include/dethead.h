@@ -244,6 +244,24 @@ int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const float* anchors,
                          int64_t* tcls, int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits,
                          const float* grad_loss, float* const* grad_p, float* out, void* assign_workspace,
                          size_t assign_workspace_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* The three loss entries on the convolution layout: conv[l] is the output of the head's 1x1 convolution of level l as it
+ * is, (bs, na*(5+nc), ny, nx) contiguous -- what Detect.forward holds before the permuted copy of
+ * object_detection/yolov5/models/yolo.py:54 -- and grad_conv[l] receives d loss / d conv[l] in the same layout, so a training
+ * step (object_detection/yolov5/train.py:329-337) needs neither that copy nor its backward.  Values as in the entries
+ * above on the permuted maps: the assigned rows and the gradient element for element, the objectness sum up to the order
+ * of its partial sums.  There is no compact logit plane to pass: the objectness logits are contiguous in this layout. */
+int dh_yolo_loss_fwd_conv(const float* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                          const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
+                          int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int dh_yolo_loss_bwd_conv(const float* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                          const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
+                          int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_conv,
+                          const void* workspace, size_t workspace_bytes, void* stream);
+int dh_yolo_loss_fwd_bwd_conv(const float* targets, int64_t nt, const float* anchors, double anchor_t, const float* const* conv,
+                              const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t* idx, float* tbox,
+                              float* anch, int64_t* tcls, int* counts, int64_t cap, const dh_yolo_hyp* hyp,
+                              const float* grad_loss, float* const* grad_conv, float* out, void* assign_workspace,
+                              size_t assign_workspace_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* dh_yolo_loss_fwd_bwd in two halves, for callers that can start the first one early.  dh_yolo_loss_positives: target
  * assignment (loss.py:169-222) and the forward of the assigned rows (loss.py:126-150) -- they read only the targets and
  * the raw maps, so they may run on another stream beside whatever produces or decodes the maps.  dh_yolo_loss_dense: the

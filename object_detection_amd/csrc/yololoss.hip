@@ -13,6 +13,13 @@
 // The objectness pass also stores d BCE / d logit per anchor (4 B each), so the backward never re-reads
 // the strided logits.  Backward = 2 launches: one streaming pass writes the whole dense gradient (zeros +
 // scaled objectness term, 16-byte stores), then the positive rows add their box / class terms.
+//
+// Convolution layout (the *_conv entries): the maps are the outputs of the head's 1x1 convolutions as they are,
+// (bs, na*no, ny, nx), i.e. what Detect.forward holds before the permuted copy of object_detection/yolov5/models/yolo.py:54,
+// and the gradient is produced in that layout too, so neither that copy nor its backward has to exist.  Cells keep their
+// numbering ((b*na + a)*ny + gj)*nx + gi; channel c of a cell sits ny*nx elements after channel c - 1.  The objectness
+// logits are then contiguous planes (coalesced reads without a compact copy) and the dense gradient is zero planes plus
+// one scaled plane per (image, anchor).
 #include "dh_iou.h"
 #include "dh_internal.h"
 #include "../../include/dethead.h"
@@ -26,6 +33,7 @@ struct yl_level {
     long cells;          // bs*na*ny*nx
     long cell_first;     // offset of this level in the owner map
     dh_fastdiv per_image;   // na*ny*nx
+    dh_fastdiv plane;       // ny*nx
     uint32_t row_first;  // first row of this level inside one image of the decoded (bs, A) planes
     unsigned blocks;     // dense-pass blocks of this level (forward: objectness blocks, backward: gradient blocks)
     unsigned fwd_blocks; // objectness-pass blocks of this level: one partial sum each
@@ -35,6 +43,7 @@ struct yl_level {
 struct yl_params {
     yl_level lvl[DH_MAX_LEVELS];
     int nl, bs, na, nc, no;
+    int conv;                  // 0: maps (bs, na, ny, nx, no); 1: convolution layout (bs, na*no, ny, nx)
     uint32_t rows_per_image;   // A = sum over levels of na*ny*nx
     long cap;
     float box, obj, cls, cls_pw, obj_pw, gamma, cp, cn, gr;
@@ -73,6 +82,8 @@ __device__ __forceinline__ float bce_grad(float x, float t, float pw, float gamm
 
 struct pos_row {
     long cell;     // index of (b,a,gj,gi) inside the level
+    size_t off;    // element offset of channel 0 of that cell inside the level's tensor
+    uint32_t cs;   // distance between consecutive channels of the cell
     int cls;
     float tb[4], an[2];
     bool ok;
@@ -87,6 +98,14 @@ __device__ __forceinline__ pos_row load_pos(const yl_params& P, const yl_level& 
     const long long b = base[r], a = base[P.cap + r], gj = base[2 * P.cap + r], gi = base[3 * P.cap + r];
     R.ok = b >= 0 && b < P.bs && a >= 0 && a < P.na && gj >= 0 && gj < L.ny && gi >= 0 && gi < L.nx;
     R.cell = ((b * P.na + a) * L.ny + gj) * L.nx + gi;
+    if (P.conv) {
+        const uint32_t hw = L.plane.d;
+        R.off = (size_t)(b * P.na + a) * P.no * hw + (size_t)(gj * L.nx + gi);
+        R.cs = hw;
+    } else {
+        R.off = (size_t)R.cell * P.no;
+        R.cs = 1;
+    }
     const float4 tb = *reinterpret_cast<const float4*>(tbox + ((size_t)l * P.cap + r) * 4);
     R.tb[0] = tb.x; R.tb[1] = tb.y; R.tb[2] = tb.z; R.tb[3] = tb.w;
     const float2 an = *reinterpret_cast<const float2*>(anch + ((size_t)l * P.cap + r) * 2);
@@ -114,8 +133,9 @@ __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const lon
         if (lane == 0) { iou_out[r] = 1.0f; cls_out[r] = 0.0f; atomicAdd(invalid, 1); }
         return;
     }
-    const float* __restrict__ ps = L.p + (size_t)R.cell * P.no;
-    const float x0 = ps[0], x1 = ps[1], x2 = ps[2], x3 = ps[3];
+    const float* __restrict__ ps = L.p + R.off;
+    const size_t cs = R.cs;
+    const float x0 = ps[0], x1 = ps[cs], x2 = ps[2 * cs], x3 = ps[3 * cs];
     const float px = dh_sigmoid(x0) * 2.0f - 0.5f, py = dh_sigmoid(x1) * 2.0f - 0.5f;          // loss.py:132
     const float tw = dh_sigmoid(x2) * 2.0f, th = dh_sigmoid(x3) * 2.0f;
     const float pw = (tw * tw) * R.an[0], ph = (th * th) * R.an[1];                             // loss.py:133
@@ -124,7 +144,7 @@ __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const lon
     float csum = 0.0f;
     if (P.nc > 1) {                                                                             // loss.py:146-149
         for (int c = lane; c < P.nc; c += 64)
-            csum += bce_value(ps[5 + c], c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma);
+            csum += bce_value(ps[(5 + c) * cs], c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma);
         csum = dh_wave_sum(csum);
     }
     if (lane == 0) {
@@ -193,6 +213,9 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
                 if (logits) {      // compact copy of the logits in decoded-row order: (bs, A)
                     const uint32_t b = dh_div((uint32_t)cell, L.per_image);
                     x = logits[(size_t)b * P.rows_per_image + L.row_first + ((uint32_t)cell - b * L.per_image.d)];
+                } else if (P.conv) {   // the objectness plane of the cell's (image, anchor): consecutive cells, consecutive words
+                    const uint32_t ba = dh_div((uint32_t)cell, L.plane);
+                    x = __builtin_nontemporal_load(L.p + ((size_t)ba * P.no + 4) * L.plane.d + ((uint32_t)cell - ba * L.plane.d));
                 } else {
                     // one 4-byte word per 340-byte row, touched once: a non-temporal load fetches just its 64-byte sector
                     // and keeps it out of the caches (measured 2.2x faster than a default load on a cold tensor)
@@ -332,6 +355,44 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const flo
     }
 }
 
+// The dense pass for the convolution layout: per (image, anchor) a span of no planes of ny*nx elements, all zero except
+// plane 4, which is the stored objectness derivative times the level's scale.  A workgroup owns 256 vectors of one span,
+// so whether a vector lies in the objectness plane is a range test (ny*nx % VEC == 0: no vector straddles planes).
+template <int VEC, bool FINAL>
+__global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, const float* __restrict__ dobj,
+                                                         const float* __restrict__ g_loss, const yl_final_args F)
+{
+    if (FINAL && blockIdx.x == 0) {
+        __shared__ double red[3 * DH_MAX_LEVELS][4];
+        yl_finalize<256>(P, F.counts, F.iou_ws, F.cls_ws, F.partial, F.invalid, F.out, red);
+    }
+    unsigned blk = blockIdx.x;
+    const int l = level_of_block(P, blk);
+    const yl_level& L = P.lvl[l];
+    const uint32_t hw = L.plane.d;
+    const uint32_t span = (uint32_t)P.no * hw;
+    const uint32_t chunks = (span / VEC + 255) / 256;
+    const uint32_t ba = blk / chunks;
+    const uint32_t e = ((blk - ba * chunks) * 256 + threadIdx.x) * VEC;
+    if (e >= span) return;
+    const float scale = g_loss[0] * (float)P.bs * P.obj * L.balance / (float)L.cells;
+    float o[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) o[k] = 0.0f;
+    if (e >= 4 * hw && e < 5 * hw) {
+        const float* __restrict__ d = dobj + L.cell_first + (size_t)ba * hw + (e - 4 * hw);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o[k] = scale * d[k];
+    }
+    float* __restrict__ g = L.g + (size_t)ba * span + e;
+    if (VEC == 4) {
+        const dh_f4 ov = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(ov, reinterpret_cast<dh_f4*>(g));
+    } else {
+        g[0] = o[0];
+    }
+}
+
 // ------------------------------------------------------------------------------------ backward: positives
 __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
@@ -346,11 +407,12 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
     if (r >= n) return;
     const pos_row R = load_pos(P, L, l, r, idx, tbox, anch, tcls);
     if (!R.ok) return;
-    const float* __restrict__ ps = L.p + (size_t)R.cell * P.no;
-    float* __restrict__ gs = L.g + (size_t)R.cell * P.no;
+    const float* __restrict__ ps = L.p + R.off;
+    float* __restrict__ gs = L.g + R.off;
+    const size_t cs = R.cs;
     const float up = g_loss[0] * (float)P.bs;
     if (lane < 4) {
-        const float x0 = ps[0], x1 = ps[1], x2 = ps[2], x3 = ps[3];
+        const float x0 = ps[0], x1 = ps[cs], x2 = ps[2 * cs], x3 = ps[3 * cs];
         const float s0 = dh_sigmoid(x0), s1 = dh_sigmoid(x1), s2 = dh_sigmoid(x2), s3 = dh_sigmoid(x3);
         const float tw = s2 * 2.0f, th = s3 * 2.0f;
         const dh_corners a = dh_from_xywh(s0 * 2.0f - 0.5f, s1 * 2.0f - 0.5f, (tw * tw) * R.an[0], (th * th) * R.an[1]);
@@ -365,12 +427,12 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
         else if (lane == 1) g = gy * 2.0f * s1 * (1.0f - s1);
         else if (lane == 2) g = gw * (2.0f * tw * R.an[0]) * (2.0f * s2 * (1.0f - s2));
         else g = gh * (2.0f * th * R.an[1]) * (2.0f * s3 * (1.0f - s3));
-        atomicAdd(gs + lane, g);            // duplicates of one cell accumulate, as index_put(accumulate) does
+        atomicAdd(gs + lane * cs, g);       // duplicates of one cell accumulate, as index_put(accumulate) does
     }
     if (P.nc > 1) {
         const float sc = up * P.cls / ((float)n * (float)P.nc);
         for (int c = lane; c < P.nc; c += 64)
-            atomicAdd(gs + 5 + c, sc * bce_grad(ps[5 + c], c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma));
+            atomicAdd(gs + (5 + c) * cs, sc * bce_grad(ps[(5 + c) * cs], c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma));
     }
 }
 
@@ -383,10 +445,11 @@ struct yl_ws {
 size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 bool make_params(const float* const* p, float* const* g, const int* ny, const int* nx, int nl, int bs, int na, int nc,
-                 long cap, const dh_yolo_hyp* hyp, bool grad_blocks, yl_params& P, yl_ws& W)
+                 long cap, const dh_yolo_hyp* hyp, bool grad_blocks, yl_params& P, yl_ws& W, bool conv = false)
 {
     if (nl < 1 || nl > DH_MAX_LEVELS || bs < 1 || na < 1 || nc < 1 || cap < 0 || !ny || !nx) return false;
     P.nl = nl; P.bs = bs; P.na = na; P.nc = nc; P.no = nc + 5; P.cap = cap;
+    P.conv = conv ? 1 : 0;
     if (hyp) {
         P.box = hyp->box; P.obj = hyp->obj; P.cls = hyp->cls; P.cls_pw = hyp->cls_pw; P.obj_pw = hyp->obj_pw;
         P.gamma = hyp->fl_gamma; P.cp = hyp->cp; P.cn = hyp->cn; P.gr = hyp->gr;
@@ -398,6 +461,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
         if (ny[l] < 1 || nx[l] < 1) return false;
         yl_level& L = P.lvl[l];
         L.per_image = dh_make_fastdiv((uint32_t)(na * ny[l] * nx[l]));
+        L.plane = dh_make_fastdiv((uint32_t)(ny[l] * nx[l]));
         L.row_first = row_first;
         row_first += (uint32_t)(na * ny[l] * nx[l]);
         L.p = p ? p[l] : nullptr;
@@ -492,6 +556,29 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
                const int64_t* tcls, const int* counts, const float* grad_loss, float* const* grad_p, const yl_final_args* F,
                hipStream_t st)
 {
+    if (P.conv) {
+        bool v4 = true;
+        for (int l = 0; l < P.nl; ++l) v4 = v4 && P.lvl[l].plane.d % 4 == 0 && dh_aligned16(grad_p[l]);
+        v4 = v4 && ((reinterpret_cast<uintptr_t>(ws) + W.off_dobj) & 15u) == 0;
+        for (int l = 0; l < P.nl; ++l) {
+            const uint32_t span = (uint32_t)P.no * P.lvl[l].plane.d;
+            P.lvl[l].blocks = (unsigned)((size_t)P.bs * P.na * ((span / (v4 ? 4 : 1) + 255) / 256));
+        }
+        const float* dobj_c = (const float*)(ws + W.off_dobj);
+        const yl_final_args none_c = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const dim3 grid_c(sum_blocks(P));
+        if (F) {
+            if (v4) hipLaunchKernelGGL((k_yl_obj_bwd_conv<4, true>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, *F);
+            else hipLaunchKernelGGL((k_yl_obj_bwd_conv<1, true>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, *F);
+        } else {
+            if (v4) hipLaunchKernelGGL((k_yl_obj_bwd_conv<4, false>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, none_c);
+            else hipLaunchKernelGGL((k_yl_obj_bwd_conv<1, false>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, none_c);
+        }
+        if (P.cap > 0)
+            hipLaunchKernelGGL(k_yl_pos_bwd, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
+                               anch, (const long long*)tcls, counts, grad_loss);
+        return dh_launch_status();
+    }
     bool vec4 = true;
     for (int l = 0; l < P.nl; ++l) vec4 = vec4 && ((size_t)P.lvl[l].cells * P.no) % 4 == 0 && dh_aligned16(grad_p[l]);
     if (!vec4) {   // scalar stores: one element per "vector"
@@ -519,15 +606,15 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
 
 }  // namespace
 
-extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
-                                const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
-                                const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out,
-                                void* workspace, size_t workspace_bytes, void* stream)
+static int loss_fwd(bool conv, const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                    const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                    const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out,
+                    void* workspace, size_t workspace_bytes, void* stream)
 {
     yl_params P;
     yl_ws W;
     if (!p || !hyp || !out || !counts || !workspace) return DH_ERR_ARG;
-    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W)) return DH_ERR_ARG;
+    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W, conv)) return DH_ERR_ARG;
     for (int l = 0; l < nl; ++l) if (!p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
@@ -535,33 +622,69 @@ extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int*
     return launch_fwd(P, W, (char*)workspace, idx, tbox, anch, tcls, counts, obj_logits, out, true, true, (hipStream_t)stream);
 }
 
-extern "C" int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                                 const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
-                                const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
-                                float* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream)
+                                const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out,
+                                void* workspace, size_t workspace_bytes, void* stream)
+{
+    return loss_fwd(false, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, obj_logits, out, workspace,
+                    workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_loss_fwd_conv(const float* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                     const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                                     const int* counts, int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace,
+                                     size_t workspace_bytes, void* stream)
+{
+    return loss_fwd(true, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, nullptr, out, workspace,
+                    workspace_bytes, stream);
+}
+
+static int loss_bwd(bool conv, const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                    const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                    const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
+                    float* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream)
 {
     yl_params P;
     yl_ws W;
     if (!p || !grad_p || !hyp || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
-    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, P, W)) return DH_ERR_ARG;
+    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, P, W, conv)) return DH_ERR_ARG;
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
     return launch_bwd(P, W, (const char*)workspace, idx, tbox, anch, tcls, counts, grad_loss, grad_p, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const float* anchors, double anchor_t,
-                                    const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
-                                    int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
-                                    const dh_yolo_hyp* hyp, const float* obj_logits, const float* grad_loss,
-                                    float* const* grad_p, float* out, void* assign_workspace, size_t assign_workspace_bytes,
-                                    void* workspace, size_t workspace_bytes, void* stream)
+extern "C" int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                                const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
+                                float* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream)
+{
+    return loss_bwd(false, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, grad_loss, grad_p, workspace,
+                    workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_loss_bwd_conv(const float* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                     const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                                     const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
+                                     float* const* grad_conv, const void* workspace, size_t workspace_bytes, void* stream)
+{
+    return loss_bwd(true, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, grad_loss, grad_conv, workspace,
+                    workspace_bytes, stream);
+}
+
+static int loss_fwd_bwd(bool conv, const float* targets, int64_t nt, const float* anchors, double anchor_t,
+                        const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                        int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
+                        const dh_yolo_hyp* hyp, const float* obj_logits, const float* grad_loss,
+                        float* const* grad_p, float* out, void* assign_workspace, size_t assign_workspace_bytes,
+                        void* workspace, size_t workspace_bytes, void* stream)
 {
     yl_params P, Pb;
     yl_ws W, Wb;
     if (!p || !grad_p || !hyp || !out || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
-    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W)) return DH_ERR_ARG;
-    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, Pb, Wb)) return DH_ERR_ARG;
+    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W, conv)) return DH_ERR_ARG;
+    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, Pb, Wb, conv)) return DH_ERR_ARG;
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
@@ -578,6 +701,30 @@ extern "C" int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const floa
     const yl_final_args F = {counts, (const float*)(ws + W.off_iou), (const float*)(ws + W.off_cls),
                              (const double*)(ws + W.off_partial), (const int*)(ws + W.off_invalid), out};
     return launch_bwd(Pb, Wb, ws, idx, tbox, anch, tcls, counts, grad_loss, grad_p, &F, (hipStream_t)stream);
+}
+
+extern "C" int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const float* anchors, double anchor_t,
+                                    const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                    int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
+                                    const dh_yolo_hyp* hyp, const float* obj_logits, const float* grad_loss,
+                                    float* const* grad_p, float* out, void* assign_workspace, size_t assign_workspace_bytes,
+                                    void* workspace, size_t workspace_bytes, void* stream)
+{
+    return loss_fwd_bwd(false, targets, nt, anchors, anchor_t, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp,
+                        obj_logits, grad_loss, grad_p, out, assign_workspace, assign_workspace_bytes, workspace, workspace_bytes,
+                        stream);
+}
+
+extern "C" int dh_yolo_loss_fwd_bwd_conv(const float* targets, int64_t nt, const float* anchors, double anchor_t,
+                                         const float* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                         int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
+                                         const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_conv, float* out,
+                                         void* assign_workspace, size_t assign_workspace_bytes, void* workspace,
+                                         size_t workspace_bytes, void* stream)
+{
+    return loss_fwd_bwd(true, targets, nt, anchors, anchor_t, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap,
+                        hyp, nullptr, grad_loss, grad_conv, out, assign_workspace, assign_workspace_bytes, workspace,
+                        workspace_bytes, stream);
 }
 
 // The fused entry in two halves, for callers that can start the first one early: assignment and the positives' forward

@@ -239,6 +239,8 @@ class Detect(nn.Module):
     """
     stride = None
     onnx_dynamic = False
+    lazy_maps = False     # training branch: return the maps as permuted views of the convolution outputs (no copy of
+    # yolo.py:54); ComputeLoss recognises them and works on the convolution outputs directly, gradients included
 
     def __init__(self, nc=80, anchors=(), ch=(), inplace=True):
         super().__init__()
@@ -265,6 +267,11 @@ class Detect(nn.Module):
     def forward(self, x):
         for i in range(self.nl):
             x[i] = self.m[i](x[i])
+        if self.training and self.lazy_maps:
+            for i in range(self.nl):
+                bs, _, ny, nx = x[i].shape
+                x[i] = x[i].contiguous().view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2)
+            return x
         if self.training or torch.is_grad_enabled() and any(c.requires_grad for c in x):
             x[:] = head_maps(x, self.na)
             return x if self.training else (detect_decode(x, self.anchors, self.stride), x)

@@ -61,13 +61,45 @@ def _assign(level_shapes, targets, anchors, anchor_t):
     return A
 
 
-def _loss_fwd(assign, hyp, nc, maps):
-    """Launch the forward kernels; returns (out[5+nl], workspace) -- the workspace feeds the backward."""
-    nl = len(maps)
-    bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
+def conv_layout_of(p):
+    """The convolution outputs behind the head maps `p`, or None.
+
+    Detect.forward with lazy_maps returns every map as the permuted VIEW x.view(bs,na,no,ny,nx).permute(0,1,3,4,2) of its
+    convolution's output instead of the contiguous copy of yolo.py:54.  Such a view has the reference's shape and values; only
+    its strides tell.  When every p[i] is one (fp32, on the device), the result is the list of (bs, na*no, ny, nx) tensors
+    they are views of, which the loss kernels read -- and write the gradient for -- as they are."""
+    convs = []
+    for x in p:
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5) or x.is_contiguous():
+            return None
+        c = x.permute(0, 1, 4, 2, 3)
+        if not c.is_contiguous():
+            return None
+        bs, na, no, ny, nx = c.shape
+        convs.append(c.reshape(bs, na * no, ny, nx))
+    return convs or None
+
+
+def _as_map_views(convs, na):
+    """(bs, na*no, ny, nx) tensors as (bs, na, ny, nx, no) views (no copy)."""
+    return [c.view(c.shape[0], na, c.shape[1] // na, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2) for c in convs]
+
+
+def _check_levels(maps, assign, nc, na, conv):
+    bs = int(maps[0].shape[0])
     for x, ny, nx in zip(maps, assign.ny, assign.nx):
-        if tuple(x.shape) != (bs, na, ny, nx, nc + 5):
-            raise RuntimeError(f"ComputeLoss: level shape {tuple(x.shape)} does not match (bs,na,ny,nx,5+nc)")
+        want = (bs, na * (nc + 5), ny, nx) if conv else (bs, na, ny, nx, nc + 5)
+        if tuple(x.shape) != want:
+            raise RuntimeError(f"ComputeLoss: level shape {tuple(x.shape)} does not match {want}")
+    return bs
+
+
+def _loss_fwd(assign, hyp, nc, maps, conv_na=0):
+    """Launch the forward kernels; returns (out[5+nl], workspace) -- the workspace feeds the backward.
+    conv_na = na: `maps` are convolution outputs (bs, na*no, ny, nx)."""
+    nl = len(maps)
+    na = conv_na or int(maps[0].shape[1])
+    bs = _check_levels(maps, assign, nc, na, bool(conv_na))
     dev = maps[0].device
     lib = L.lib()
     ny, nx = L.int_array(assign.ny), L.int_array(assign.nx)
@@ -79,6 +111,13 @@ def _loss_fwd(assign, hyp, nc, maps):
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     # when the inference decode has just read these very maps (validation: val.py:194-198 evaluates the loss on the
     # maps it decoded), it left a compact copy of their objectness logits; read that instead of the strided column
+    if conv_na:
+        with L.device_guard(dev):
+            L.check(lib.dh_yolo_loss_fwd_conv(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
+                                              L.ptr(assign.anch), L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap,
+                                              ctypes.byref(hyp), L.ptr(out), L.ptr(ws), ws_bytes, L.stream()),
+                    "dh_yolo_loss_fwd_conv")
+        return out, ws
     logits = objectness_logits(maps)
     with L.device_guard(dev):
         L.check(lib.dh_yolo_loss_fwd(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
@@ -88,15 +127,17 @@ def _loss_fwd(assign, hyp, nc, maps):
     return out, ws
 
 
-def _loss_bwd(assign, hyp, nc, maps, ws, g_loss):
-    """Launch the backward kernels for upstream gradient g_loss (1 float on the device); returns grads."""
+def _loss_bwd(assign, hyp, nc, maps, ws, g_loss, conv_na=0):
+    """Launch the backward kernels for upstream gradient g_loss (1 float on the device); returns grads
+    (in the layout of `maps`: convolution layout when conv_na = na)."""
     nl = len(maps)
-    bs, na = int(maps[0].shape[0]), int(maps[0].shape[1])
+    bs, na = int(maps[0].shape[0]), conv_na or int(maps[0].shape[1])
     grads = [torch.empty_like(x) for x in maps]
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
+    entry = L.lib().dh_yolo_loss_bwd_conv if conv_na else L.lib().dh_yolo_loss_bwd
     with L.device_guard(maps[0].device):
-        L.check(L.lib().dh_yolo_loss_bwd(ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc,
+        L.check(entry(ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc,
                                          L.ptr(assign.idx), L.ptr(assign.tbox), L.ptr(assign.anch),
                                          L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap, ctypes.byref(hyp),
                                          L.ptr(g_loss), gptrs, L.ptr(ws), ws.numel(), L.stream()), "dh_yolo_loss_bwd")
@@ -114,8 +155,9 @@ def _one(device):
     return hit
 
 
-def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss):
-    """Assignment, loss forward and backward through the single fused entry; returns (assignment, out, grads)."""
+def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss, conv=False):
+    """Assignment, loss forward and backward through the single fused entry; returns (assignment, out, grads).
+    conv: `maps` are convolution outputs (bs, na*no, ny, nx) and so are the gradients."""
     tg = L.dev_f32(targets, "targets").contiguous()
     if tg.dim() != 2 or tg.shape[1] != 6:
         raise RuntimeError(f"targets must be (nt,6) [image,class,x,y,w,h], got {tuple(targets.shape)}")
@@ -123,10 +165,7 @@ def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss):
     nl, na = int(anc.shape[0]), int(anc.shape[1])
     dev = maps[0].device
     A = _Assignment(shapes, tg.shape[0], na, nl, dev)
-    bs = int(maps[0].shape[0])
-    for x, ny_, nx_ in zip(maps, A.ny, A.nx):
-        if tuple(x.shape) != (bs, na, ny_, nx_, nc + 5):
-            raise RuntimeError(f"ComputeLoss: level shape {tuple(x.shape)} does not match (bs,na,ny,nx,5+nc)")
+    bs = _check_levels(maps, A, nc, na, conv)
     lib = L.lib()
     ny, nx = L.int_array(A.ny), L.int_array(A.nx)
     aws_bytes = lib.dh_build_targets_workspace(nl, na, A.nt)
@@ -138,6 +177,13 @@ def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss):
     grads = [torch.empty_like(x) for x in maps]
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
+    if conv:
+        with L.device_guard(dev):
+            L.check(lib.dh_yolo_loss_fwd_bwd_conv(L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc,
+                                                  L.ptr(A.idx), L.ptr(A.tbox), L.ptr(A.anch), L.ptr(A.tcls), L.ptr(A.counts),
+                                                  A.cap, ctypes.byref(hyp), L.ptr(grad_loss), gptrs, L.ptr(out), L.ptr(aws),
+                                                  aws_bytes, L.ptr(ws), ws_bytes, L.stream()), "dh_yolo_loss_fwd_bwd_conv")
+        return A, out, grads
     logits = objectness_logits(maps)
     with L.device_guard(dev):
         L.check(lib.dh_yolo_loss_fwd_bwd(L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc,
@@ -220,6 +266,17 @@ def _loss_dense(st, nc, maps, grad_loss):
 class _YoloLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, assign, hyp, nc, *p):
+        convs = conv_layout_of(p)
+        if convs is not None:       # lazy maps: the kernels work on the convolution outputs themselves
+            na = int(p[0].shape[1])
+            out, ws = _loss_fwd(assign, hyp, nc, convs, conv_na=na)
+            ctx.save_for_backward(*convs)
+            ctx.state = (assign, hyp, nc, ws, [x.dtype for x in p])
+            ctx.conv_na = na
+            loss, rest = out[0:1], out[1:]
+            ctx.mark_non_differentiable(rest)
+            return loss, rest
+        ctx.conv_na = 0
         maps = [L.dev_f32(x, f"p[{i}]").contiguous() for i, x in enumerate(p)]
         out, ws = _loss_fwd(assign, hyp, nc, maps)
         ctx.save_for_backward(*maps)
@@ -232,6 +289,10 @@ class _YoloLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g_out):
         maps = ctx.saved_tensors
         assign, hyp, nc, ws, dtypes = ctx.state
+        if ctx.conv_na:     # gradients in the convolution layout, handed back as views of the maps' shape: the permute and
+            # view nodes between the convolution and the loss pass them on without a copy
+            grads = _loss_bwd(assign, hyp, nc, maps, ws, g_loss.reshape(1).float().contiguous(), conv_na=ctx.conv_na)
+            return (None, None, None) + tuple(_as_map_views(grads, ctx.conv_na))
         grads = _loss_bwd(assign, hyp, nc, maps, ws, g_loss.reshape(1).float().contiguous())
         return (None, None, None) + tuple(gr if dt == torch.float32 else gr.to(dt) for gr, dt in zip(grads, dtypes))
 
@@ -319,6 +380,15 @@ class ComputeLoss:
         """
         if self.sort_obj_iou or self.autobalance:
             raise NotImplementedError("forward_backward supports neither sort_obj_iou nor autobalance")
+        convs = conv_layout_of(p) if assignment is None and positives is None else None
+        if convs is not None:       # lazy maps (see conv_layout_of): gradients come back as views of the same kind
+            shapes = [(int(x.shape[2]), int(x.shape[3])) for x in p]
+            g = _one(convs[0].device) if grad_loss is None else grad_loss
+            assign, out, grads = _loss_fused(shapes, targets, self.anchors, self.hyp['anchor_t'], self._hyp_struct(), int(self.nc),
+                                             [c.detach() for c in convs], g.reshape(1).float().contiguous(), conv=True)
+            self.last_positive_counts = assign.counts
+            self.last_stats = out[1:5]
+            return out[0:1], out[1:4], _as_map_views(grads, int(p[0].shape[1]))
         maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
         shapes = [(int(x.shape[2]), int(x.shape[3])) for x in maps]
         hyp = self._hyp_struct()

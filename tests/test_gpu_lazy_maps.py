@@ -1,0 +1,140 @@
+"""GPU parity of the loss on the convolution layout.  With Detect.lazy_maps the training branch hands the maps out as
+permuted views of the convolution outputs (no copy of yolo.py:54); ComputeLoss recognises such views and reads the
+convolution outputs, and writes their gradient, directly.  The reference for every number here is the path other tests
+tie to the oracle and the reference's fixtures: the same loss on the contiguous maps, with autograd (or head_maps'
+backward) carrying the gradient back to the convolution layout."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo as oy
+from tests._synth import synth_targets
+from tests.test_gpu_yolo_loss import close, make_loss
+
+pytestmark = pytest.mark.gpu
+
+
+def _convs(rs, bs, na, no, shapes):
+    out = []
+    for ny, nx in shapes:
+        x = rs.normal(0, 1, (bs, na * no, ny, nx)).astype(np.float32)
+        v = x.reshape(bs, na, no, ny, nx)
+        v[:, :, 4] -= 4.0
+        v[:, :, 5:] -= 3.0
+        out.append(torch.from_numpy(x).cuda())
+    return out
+
+
+def _views(convs, na):
+    return [c.view(c.shape[0], na, c.shape[1] // na, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2) for c in convs]
+
+
+CASES = [
+    # bs, nc, [(ny, nx)], nt, hyp overrides
+    (8, 80, [(80, 80), (40, 40), (20, 20)], 80, {}),
+    (3, 7, [(12, 20), (6, 10), (3, 5)], 40, {}),                       # ny*nx not a multiple of 4 on the last level -> scalar stores
+    (2, 1, [(16, 16), (8, 8), (4, 4)], 12, {}),                        # one class: no class term
+    (4, 20, [(20, 20), (10, 10), (5, 5)], 300, dict(fl_gamma=1.5, label_smoothing=0.1, cls_pw=0.7, obj_pw=1.3)),
+    (2, 5, [(8, 8), (4, 4), (2, 2)], 0, {}),                           # no targets
+]
+
+
+@pytest.mark.parametrize("bs,nc,shapes,nt,over", CASES)
+def test_loss_on_lazy_maps_equals_loss_on_contiguous_maps(bs, nc, shapes, nt, over):
+    from object_detection_amd.yolo_loss import conv_layout_of
+    rs = np.random.RandomState(31)
+    hyp = dict(oy.HYP_SCRATCH)
+    hyp.update(over)
+    anchors = oy.grid_anchors()
+    crit = make_loss(anchors, nc, hyp)
+    targets = torch.from_numpy(synth_targets(rs, nt, bs, nc)).cuda()
+    if nt >= 12:
+        targets[1:4] = targets[0]                      # four rows on one cell: the owner rule and accumulating gradients
+    base = _convs(rs, bs, 3, nc + 5, shapes)
+
+    a = [c.clone().requires_grad_() for c in base]
+    maps = [v.contiguous() for v in _views(a, 3)]
+    assert conv_layout_of(maps) is None
+    loss_a, items_a = crit(maps, targets)
+    (loss_a * 3.0).backward()
+
+    b = [c.clone().requires_grad_() for c in base]
+    views = _views(b, 3)
+    assert conv_layout_of(views) is not None
+    loss_b, items_b = crit(views, targets)
+    (loss_b * 3.0).backward()
+
+    close(loss_b, loss_a, rtol=1e-6)
+    close(items_b, items_a, rtol=1e-6)
+    for ga, gb in zip(a, b):
+        assert gb.grad.is_contiguous() and gb.grad.shape == ga.grad.shape
+        close(gb.grad, ga.grad, rtol=1e-6, floor=1e-9)
+        # everything but cells with three or more assigned rows (fp32 add order) is the same float
+        assert float((gb.grad != ga.grad).float().mean()) < 2e-3
+
+    # the fused entry on the same views
+    loss_c, items_c, grads_c = crit.forward_backward(_views(base, 3), targets, grad_loss=torch.tensor([3.0], device="cuda"))
+    close(loss_c, loss_a, rtol=1e-6)
+    close(items_c, items_a, rtol=1e-6)
+    for ga, gc, c in zip(a, grads_c, base):
+        assert gc.shape == (bs, 3, c.shape[2], c.shape[3], nc + 5)
+        back = gc.permute(0, 1, 4, 2, 3)
+        assert back.is_contiguous()
+        close(back.reshape(ga.grad.shape), ga.grad, rtol=1e-6, floor=1e-9)
+
+
+def test_lazy_maps_against_the_oracle():
+    rs = np.random.RandomState(32)
+    bs, nc, shapes = 4, 12, [(16, 24), (8, 12), (4, 6)]
+    anchors = oy.grid_anchors()
+    crit = make_loss(anchors, nc, dict(oy.HYP_SCRATCH))
+    targets = synth_targets(rs, 60, bs, nc)
+    convs = [c.requires_grad_() for c in _convs(rs, bs, 3, nc + 5, shapes)]
+    loss, items = crit(_views(convs, 3), torch.from_numpy(targets).cuda())
+    loss.backward()
+    ref = [c.detach().cpu().requires_grad_() for c in convs]
+    want, want_items = oy.YoloLossOracle(anchors, dict(oy.HYP_SCRATCH), nc=nc)([v.contiguous() for v in _views(ref, 3)],
+                                                                               torch.from_numpy(targets))
+    want.backward()
+    close(loss, want)
+    close(items, want_items)
+    for c, r in zip(convs, ref):
+        close(c.grad, r.grad, floor=1e-7)
+
+
+def test_detect_module_with_lazy_maps_trains_like_the_copying_one():
+    from object_detection_amd.yolo import Detect
+    from object_detection_amd.yolo_loss import ComputeLoss, conv_layout_of
+
+    class Model(torch.nn.Module):
+        def __init__(self, det):
+            super().__init__()
+            self.model = torch.nn.ModuleList([det])
+            self.hyp = dict(oy.HYP_SCRATCH)
+
+    torch.manual_seed(5)
+    dets = []
+    for lazy in (False, True):
+        torch.manual_seed(5)
+        det = Detect(nc=9, anchors=oy.YOLOV5S_ANCHORS_PX, ch=(8, 16, 32)).cuda().train()
+        det.stride = torch.tensor(oy.YOLOV5S_STRIDES)
+        det.anchors /= det.stride.view(-1, 1, 1).cuda()
+        det.lazy_maps = lazy
+        dets.append(det)
+    rs = np.random.RandomState(6)
+    feats = [torch.randn(4, c, 64 // s, 96 // s, device="cuda") for c, s in zip((8, 16, 32), (8, 16, 32))]
+    targets = torch.from_numpy(synth_targets(rs, 30, 4, 9)).cuda()
+    outs = []
+    for det in dets:
+        crit = ComputeLoss(Model(det))
+        p = det([f.clone() for f in feats])
+        assert (conv_layout_of(p) is not None) == det.lazy_maps
+        assert [tuple(x.shape) for x in p] == [(4, 3, 64 // s, 96 // s, 14) for s in (8, 16, 32)]
+        loss, items = crit(p, targets)
+        loss.backward()
+        outs.append((loss.detach(), items, [m.weight.grad.clone() for m in det.m], [m.bias.grad.clone() for m in det.m]))
+    close(outs[1][0], outs[0][0], rtol=1e-6)
+    close(outs[1][1], outs[0][1], rtol=1e-6)
+    for k in (2, 3):
+        for g1, g0 in zip(outs[1][k], outs[0][k]):
+            close(g1, g0, rtol=1e-4, floor=1e-6)          # the convolution's own backward sums in fp32

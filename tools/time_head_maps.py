@@ -95,6 +95,44 @@ rows += [
     ("Detect eval + NMS(0.001, multi-label)", lambda: G.non_max_suppression(yolo.head_maps_decode(convs, na, anchors, stride)[0], **VAL), elems * 4),
     ("conv_nms(0.001, multi-label)", lambda: G.conv_nms(convs, na, anchors, stride, **VAL), elems * 4),
 ]
+# the training step's head: maps from the convolution outputs, loss, backward down to the convolution outputs
+from object_detection_amd.yolo_loss import ComputeLoss  # noqa: E402
+
+
+class _Det:
+    na, nl, nc, anchors, stride = na, 3, 80, anchors, stride
+
+
+class _Model(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = [_Det()]
+        self.hyp = dict(box=0.05, cls=0.5, cls_pw=1.0, obj=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)
+
+
+crit = ComputeLoss(_Model())
+nt = 10 * bs
+targets = torch.cat((torch.randint(0, bs, (nt, 1)).float(), torch.randint(0, 80, (nt, 1)).float(), torch.rand(nt, 2),
+                     torch.exp(torch.empty(nt, 2).uniform_(-4.6, -0.5))), 1).to(dev)
+leaves = [c.clone().requires_grad_() for c in convs]
+
+
+def train_head(make_maps):
+    # autograd.grad hands the gradients over as they arrive (backward() would add AccumulateGrad's clone of each, which a
+    # convolution's backward -- the real consumer -- does not make)
+    loss, _ = crit(make_maps(leaves), targets)
+    return [g.contiguous() for g in torch.autograd.grad(loss, leaves)]      # contiguous: what the convolution's backward asks for
+
+
+def lazy(cs):
+    return [c.view(bs, na, no, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2) for c in cs]
+
+
+rows += [
+    ("train head: torch permute copy + loss + backward", lambda: train_head(lambda cs: [v.contiguous() for v in lazy(cs)]), 5 * elems * 4),
+    ("train head: head_maps + loss + backward", lambda: train_head(lambda cs: yolo.head_maps(cs, na)), 5 * elems * 4),
+    ("train head: lazy maps + loss + backward", lambda: train_head(lazy), elems * 4),
+]
 for name, fn, nbytes in rows:
     ms = timed(fn)
     print(f"{name:42s} {ms * 1e3:8.1f} us   {nbytes / ms / 1e6:8.1f} GB/s of its own algorithmic bytes", flush=True)
