@@ -89,6 +89,7 @@ struct pos_row {
     bool ok;
 };
 
+template <bool CONV>
 __device__ __forceinline__ pos_row load_pos(const yl_params& P, const yl_level& L, int l, long r,
                                             const long long* __restrict__ idx, const float* __restrict__ tbox,
                                             const float* __restrict__ anch, const long long* __restrict__ tcls)
@@ -98,7 +99,7 @@ __device__ __forceinline__ pos_row load_pos(const yl_params& P, const yl_level& 
     const long long b = base[r], a = base[P.cap + r], gj = base[2 * P.cap + r], gi = base[3 * P.cap + r];
     R.ok = b >= 0 && b < P.bs && a >= 0 && a < P.na && gj >= 0 && gj < L.ny && gi >= 0 && gi < L.nx;
     R.cell = ((b * P.na + a) * L.ny + gj) * L.nx + gi;
-    if (P.conv) {
+    if (CONV) {
         const uint32_t hw = L.plane.d;
         R.off = (size_t)(b * P.na + a) * P.no * hw + (size_t)(gj * L.nx + gi);
         R.cs = hw;
@@ -115,6 +116,7 @@ __device__ __forceinline__ pos_row load_pos(const yl_params& P, const yl_level& 
 }
 
 // ------------------------------------------------------------------------------------ forward: positives
+template <bool CONV>
 __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
                                                     const long long* __restrict__ tcls, const int* __restrict__ counts,
@@ -126,7 +128,7 @@ __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const lon
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= counts[l]) return;
-    const pos_row R = load_pos(P, L, l, r, idx, tbox, anch, tcls);
+    const pos_row R = load_pos<CONV>(P, L, l, r, idx, tbox, anch, tcls);
     float* __restrict__ iou_out = iou_ws + (size_t)l * P.cap;
     float* __restrict__ cls_out = cls_ws + (size_t)l * P.cap;
     if (!R.ok) {      // image / anchor index outside the tensors: contributes nothing, counted for the caller
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const lon
         return;
     }
     const float* __restrict__ ps = L.p + R.off;
-    const size_t cs = R.cs;
+    const size_t cs = CONV ? R.cs : 1;      // a compile-time 1 for the map layout: channel offsets stay immediates
     const float x0 = ps[0], x1 = ps[cs], x2 = ps[2 * cs], x3 = ps[3 * cs];
     const float px = dh_sigmoid(x0) * 2.0f - 0.5f, py = dh_sigmoid(x1) * 2.0f - 0.5f;          // loss.py:132
     const float tw = dh_sigmoid(x2) * 2.0f, th = dh_sigmoid(x3) * 2.0f;
@@ -174,7 +176,7 @@ __device__ __forceinline__ float tobj_of(const yl_params& P, int own, const floa
 
 // VEC: a thread owns four consecutive cells (same image: the cells per image and level are a multiple of four) and
 // moves the compact logits, the owner words and the stored derivative as 16-byte vectors.
-template <bool VEC>
+template <bool VEC, bool CONV = false>
 __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int* __restrict__ owner,
                                                     const float* __restrict__ iou_ws, double* __restrict__ partial,
                                                     float* __restrict__ dobj, const float* __restrict__ logits)
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
                 if (logits) {      // compact copy of the logits in decoded-row order: (bs, A)
                     const uint32_t b = dh_div((uint32_t)cell, L.per_image);
                     x = logits[(size_t)b * P.rows_per_image + L.row_first + ((uint32_t)cell - b * L.per_image.d)];
-                } else if (P.conv) {   // the objectness plane of the cell's (image, anchor): consecutive cells, consecutive words
+                } else if (CONV) {     // the objectness plane of the cell's (image, anchor): consecutive cells, consecutive words
                     const uint32_t ba = dh_div((uint32_t)cell, L.plane);
                     x = __builtin_nontemporal_load(L.p + ((size_t)ba * P.no + 4) * L.plane.d + ((uint32_t)cell - ba * L.plane.d));
                 } else {
@@ -394,6 +396,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, cons
 }
 
 // ------------------------------------------------------------------------------------ backward: positives
+template <bool CONV>
 __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
                                                     const long long* __restrict__ tcls, const int* __restrict__ counts,
@@ -405,11 +408,11 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = counts[l];
     if (r >= n) return;
-    const pos_row R = load_pos(P, L, l, r, idx, tbox, anch, tcls);
+    const pos_row R = load_pos<CONV>(P, L, l, r, idx, tbox, anch, tcls);
     if (!R.ok) return;
     const float* __restrict__ ps = L.p + R.off;
     float* __restrict__ gs = L.g + R.off;
-    const size_t cs = R.cs;
+    const size_t cs = CONV ? R.cs : 1;
     const float up = g_loss[0] * (float)P.bs;
     if (lane < 4) {
         const float x0 = ps[0], x1 = ps[cs], x2 = ps[2 * cs], x3 = ps[3 * cs];
@@ -534,15 +537,20 @@ int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx,
     // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
     // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
     if (fill && hipMemsetAsync(owner, 0xFF, W.off_iou - W.off_owner, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (P.cap > 0 && (parts & 1))
-        hipLaunchKernelGGL(k_yl_pos_fwd, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
-                           anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+    if (P.cap > 0 && (parts & 1)) {
+        if (P.conv) hipLaunchKernelGGL(k_yl_pos_fwd<true>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
+                                       (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+        else hipLaunchKernelGGL(k_yl_pos_fwd<false>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
+                                (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+    }
     if (!(parts & 2)) return dh_launch_status();
     // 16-byte vectors when the compact logits are there and every level keeps four consecutive cells inside one image
     bool vec = obj_logits != nullptr && dh_aligned16(obj_logits) && P.rows_per_image % 4 == 0;
     for (int l = 0; l < P.nl; ++l)
         vec = vec && P.lvl[l].per_image.d % 4 == 0 && P.lvl[l].row_first % 4 == 0 && P.lvl[l].cell_first % 4 == 0;
-    if (vec) hipLaunchKernelGGL(k_yl_obj_fwd<true>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
+    if (P.conv) hipLaunchKernelGGL((k_yl_obj_fwd<false, true>), dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
+                                   (float*)(ws + W.off_dobj), obj_logits);
+    else if (vec) hipLaunchKernelGGL(k_yl_obj_fwd<true>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
                                 (float*)(ws + W.off_dobj), obj_logits);
     else hipLaunchKernelGGL(k_yl_obj_fwd<false>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
                             (float*)(ws + W.off_dobj), obj_logits);
@@ -575,8 +583,8 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
             else hipLaunchKernelGGL((k_yl_obj_bwd_conv<1, false>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, none_c);
         }
         if (P.cap > 0)
-            hipLaunchKernelGGL(k_yl_pos_bwd, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
-                               anch, (const long long*)tcls, counts, grad_loss);
+            hipLaunchKernelGGL(k_yl_pos_bwd<true>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx,
+                               tbox, anch, (const long long*)tcls, counts, grad_loss);
         return dh_launch_status();
     }
     bool vec4 = true;
@@ -599,7 +607,7 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
         else hipLaunchKernelGGL((k_yl_obj_bwd<1, false>), grid, dim3(256), 0, st, P, dobj, grad_loss, nod, none);
     }
     if (P.cap > 0)
-        hipLaunchKernelGGL(k_yl_pos_bwd, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
+        hipLaunchKernelGGL(k_yl_pos_bwd<false>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
                            anch, (const long long*)tcls, counts, grad_loss);
     return dh_launch_status();
 }
