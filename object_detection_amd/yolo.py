@@ -177,8 +177,9 @@ def head_maps(convs, na):
     return list(_HeadMaps.apply(na, *convs))
 
 
-def head_maps_decode(convs, na, anchors, stride):
+def head_maps_decode(convs, na, anchors, stride, lazy=False):
     """Eval branch of Detect.forward after the convolutions (yolo.py:53-70): returns (decoded (bs, A, no), head maps).
+    lazy: the maps are returned as permuted views of the convolution outputs instead of being written (fp32 only).
     One launch reads the convolution outputs once and writes both; the results equal head_maps + detect_decode bit for bit.
     A half-precision head keeps fp16 maps; the decoded tensor is fp32, as detect_decode returns it for fp16 maps."""
     convs = [c.detach() for c in convs]
@@ -191,14 +192,18 @@ def head_maps_decode(convs, na, anchors, stride):
     dev = convs[0].device
     total = sum(na * h * w for h, w in zip(ny, nx))
     anchor_px, strides = _anchor_pixels(anchors, stride)
-    maps = [torch.empty((bs, na, h, w, no), dtype=convs[0].dtype, device=dev) for h, w in zip(ny, nx)]
+    lazy = lazy and convs[0].dtype == torch.float32
+    if lazy:
+        maps = [c.view(bs, na, no, h, w).permute(0, 1, 3, 4, 2) for c, h, w in zip(convs, ny, nx)]
+    else:
+        maps = [torch.empty((bs, na, h, w, no), dtype=convs[0].dtype, device=dev) for h, w in zip(ny, nx)]
     out = torch.empty((bs, total, no), dtype=torch.float32, device=dev)
     planes = torch.empty((2, bs, total), dtype=torch.float32, device=dev)
     entry = L.lib().dh_yolo_head_maps_f16 if convs[0].dtype == torch.float16 else L.lib().dh_yolo_head_maps
     with L.device_guard(dev):
         made_on = L.raw_stream()
         L.check(entry((L.c_void_p * nl)(*[c.data_ptr() for c in convs]),
-                                          (L.c_void_p * nl)(*[m.data_ptr() for m in maps]), L.int_array(ny), L.int_array(nx),
+                                          None if lazy else (L.c_void_p * nl)(*[m.data_ptr() for m in maps]), L.int_array(ny), L.int_array(nx),
                                           nl, bs, na, no, anchor_px, strides, L.ptr(out), L.ptr(planes[0]), L.ptr(planes[1]),
                                           L.c_void_p(made_on)), "dh_yolo_head_maps")
     _remember_planes(out, maps, planes[0], planes[1], made_on)
@@ -239,8 +244,8 @@ class Detect(nn.Module):
     """
     stride = None
     onnx_dynamic = False
-    lazy_maps = False     # training branch: return the maps as permuted views of the convolution outputs (no copy of
-    # yolo.py:54); ComputeLoss recognises them and works on the convolution outputs directly, gradients included
+    lazy_maps = False     # return the maps as permuted views of the convolution outputs (no copy of yolo.py:54);
+    # ComputeLoss recognises them and works on the convolution outputs directly, gradients included
 
     def __init__(self, nc=80, anchors=(), ch=(), inplace=True):
         super().__init__()
@@ -275,5 +280,5 @@ class Detect(nn.Module):
         if self.training or torch.is_grad_enabled() and any(c.requires_grad for c in x):
             x[:] = head_maps(x, self.na)
             return x if self.training else (detect_decode(x, self.anchors, self.stride), x)
-        z, x[:] = head_maps_decode(x, self.na, self.anchors, self.stride)
+        z, x[:] = head_maps_decode(x, self.na, self.anchors, self.stride, lazy=self.lazy_maps)
         return z, x
