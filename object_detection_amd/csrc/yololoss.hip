@@ -43,6 +43,7 @@ struct yl_level {
 struct yl_params {
     yl_level lvl[DH_MAX_LEVELS];
     int nl, bs, na, nc, no;
+    int half;                  // convolution layout only: the tensors hold fp16 elements (the gradient stays fp32)
     int conv;                  // 0: maps (bs, na, ny, nx, no); 1: convolution layout (bs, na*no, ny, nx)
     uint32_t rows_per_image;   // A = sum over levels of na*ny*nx
     long cap;
@@ -78,6 +79,16 @@ __device__ __forceinline__ float bce_grad(float x, float t, float pw, float gamm
     const float mf = powf(om, gamma);
     const float dmf = -gamma * powf(om, gamma - 1.0f) * ((2.0f * t - 1.0f) * s * (1.0f - s));
     return af * (d * mf + l * dmf);
+}
+
+// element k of a tensor whose elements are fp32 or fp16 (widened on load; the arithmetic is fp32 either way)
+template <typename T> __device__ __forceinline__ float ld_el(const float* base, size_t k)
+{
+    return (float)reinterpret_cast<const T*>(base)[k];
+}
+template <typename T> __device__ __forceinline__ float ld_el_nt(const float* base, size_t k)
+{
+    return (float)__builtin_nontemporal_load(reinterpret_cast<const T*>(base) + k);
 }
 
 struct pos_row {
@@ -116,7 +127,7 @@ __device__ __forceinline__ pos_row load_pos(const yl_params& P, const yl_level& 
 }
 
 // ------------------------------------------------------------------------------------ forward: positives
-template <bool CONV>
+template <bool CONV, typename T = float>
 __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
                                                     const long long* __restrict__ tcls, const int* __restrict__ counts,
@@ -135,9 +146,10 @@ __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const lon
         if (lane == 0) { iou_out[r] = 1.0f; cls_out[r] = 0.0f; atomicAdd(invalid, 1); }
         return;
     }
-    const float* __restrict__ ps = L.p + R.off;
     const size_t cs = CONV ? R.cs : 1;      // a compile-time 1 for the map layout: channel offsets stay immediates
-    const float x0 = ps[0], x1 = ps[cs], x2 = ps[2 * cs], x3 = ps[3 * cs];
+    const float* __restrict__ ps = L.p + (sizeof(T) == 4 ? R.off : 0);       // fp16: element offsets are applied by ld_el
+    const size_t e0 = sizeof(T) == 4 ? 0 : R.off;
+    const float x0 = ld_el<T>(ps, e0), x1 = ld_el<T>(ps, e0 + cs), x2 = ld_el<T>(ps, e0 + 2 * cs), x3 = ld_el<T>(ps, e0 + 3 * cs);
     const float px = dh_sigmoid(x0) * 2.0f - 0.5f, py = dh_sigmoid(x1) * 2.0f - 0.5f;          // loss.py:132
     const float tw = dh_sigmoid(x2) * 2.0f, th = dh_sigmoid(x3) * 2.0f;
     const float pw = (tw * tw) * R.an[0], ph = (th * th) * R.an[1];                             // loss.py:133
@@ -146,7 +158,7 @@ __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const lon
     float csum = 0.0f;
     if (P.nc > 1) {                                                                             // loss.py:146-149
         for (int c = lane; c < P.nc; c += 64)
-            csum += bce_value(ps[(5 + c) * cs], c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma);
+            csum += bce_value(ld_el<T>(ps, e0 + (5 + c) * cs), c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma);
         csum = dh_wave_sum(csum);
     }
     if (lane == 0) {
@@ -176,7 +188,7 @@ __device__ __forceinline__ float tobj_of(const yl_params& P, int own, const floa
 
 // VEC: a thread owns four consecutive cells (same image: the cells per image and level are a multiple of four) and
 // moves the compact logits, the owner words and the stored derivative as 16-byte vectors.
-template <bool VEC, bool CONV = false>
+template <bool VEC, bool CONV = false, typename T = float>
 __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int* __restrict__ owner,
                                                     const float* __restrict__ iou_ws, double* __restrict__ partial,
                                                     float* __restrict__ dobj, const float* __restrict__ logits)
@@ -217,7 +229,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
                     x = logits[(size_t)b * P.rows_per_image + L.row_first + ((uint32_t)cell - b * L.per_image.d)];
                 } else if (CONV) {     // the objectness plane of the cell's (image, anchor): consecutive cells, consecutive words
                     const uint32_t ba = dh_div((uint32_t)cell, L.plane);
-                    x = __builtin_nontemporal_load(L.p + ((size_t)ba * P.no + 4) * L.plane.d + ((uint32_t)cell - ba * L.plane.d));
+                    x = ld_el_nt<T>(L.p, ((size_t)ba * P.no + 4) * L.plane.d + ((uint32_t)cell - ba * L.plane.d));
                 } else {
                     // one 4-byte word per 340-byte row, touched once: a non-temporal load fetches just its 64-byte sector
                     // and keeps it out of the caches (measured 2.2x faster than a default load on a cold tensor)
@@ -396,7 +408,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, cons
 }
 
 // ------------------------------------------------------------------------------------ backward: positives
-template <bool CONV>
+template <bool CONV, typename T = float>
 __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
                                                     const long long* __restrict__ tcls, const int* __restrict__ counts,
@@ -410,12 +422,13 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
     if (r >= n) return;
     const pos_row R = load_pos<CONV>(P, L, l, r, idx, tbox, anch, tcls);
     if (!R.ok) return;
-    const float* __restrict__ ps = L.p + R.off;
-    float* __restrict__ gs = L.g + R.off;
+    const float* __restrict__ ps = L.p + (sizeof(T) == 4 ? R.off : 0);
+    const size_t e0 = sizeof(T) == 4 ? 0 : R.off;
+    float* __restrict__ gs = L.g + R.off;       // the gradient is fp32 whatever the maps hold
     const size_t cs = CONV ? R.cs : 1;
     const float up = g_loss[0] * (float)P.bs;
     if (lane < 4) {
-        const float x0 = ps[0], x1 = ps[cs], x2 = ps[2 * cs], x3 = ps[3 * cs];
+        const float x0 = ld_el<T>(ps, e0), x1 = ld_el<T>(ps, e0 + cs), x2 = ld_el<T>(ps, e0 + 2 * cs), x3 = ld_el<T>(ps, e0 + 3 * cs);
         const float s0 = dh_sigmoid(x0), s1 = dh_sigmoid(x1), s2 = dh_sigmoid(x2), s3 = dh_sigmoid(x3);
         const float tw = s2 * 2.0f, th = s3 * 2.0f;
         const dh_corners a = dh_from_xywh(s0 * 2.0f - 0.5f, s1 * 2.0f - 0.5f, (tw * tw) * R.an[0], (th * th) * R.an[1]);
@@ -435,7 +448,7 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
     if (P.nc > 1) {
         const float sc = up * P.cls / ((float)n * (float)P.nc);
         for (int c = lane; c < P.nc; c += 64)
-            atomicAdd(gs + (5 + c) * cs, sc * bce_grad(ps[(5 + c) * cs], c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma));
+            atomicAdd(gs + (5 + c) * cs, sc * bce_grad(ld_el<T>(ps, e0 + (5 + c) * cs), c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma));
     }
 }
 
@@ -453,6 +466,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
     if (nl < 1 || nl > DH_MAX_LEVELS || bs < 1 || na < 1 || nc < 1 || cap < 0 || !ny || !nx) return false;
     P.nl = nl; P.bs = bs; P.na = na; P.nc = nc; P.no = nc + 5; P.cap = cap;
     P.conv = conv ? 1 : 0;
+    P.half = 0;
     if (hyp) {
         P.box = hyp->box; P.obj = hyp->obj; P.cls = hyp->cls; P.cls_pw = hyp->cls_pw; P.obj_pw = hyp->obj_pw;
         P.gamma = hyp->fl_gamma; P.cp = hyp->cp; P.cn = hyp->cn; P.gr = hyp->gr;
@@ -538,7 +552,9 @@ int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx,
     // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
     if (fill && hipMemsetAsync(owner, 0xFF, W.off_iou - W.off_owner, st) != hipSuccess) return DH_ERR_LAUNCH;
     if (P.cap > 0 && (parts & 1)) {
-        if (P.conv) hipLaunchKernelGGL(k_yl_pos_fwd<true>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
+        if (P.conv && P.half) hipLaunchKernelGGL((k_yl_pos_fwd<true, _Float16>), dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
+                                                 (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+        else if (P.conv) hipLaunchKernelGGL(k_yl_pos_fwd<true>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
                                        (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
         else hipLaunchKernelGGL(k_yl_pos_fwd<false>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
                                 (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
@@ -548,7 +564,9 @@ int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx,
     bool vec = obj_logits != nullptr && dh_aligned16(obj_logits) && P.rows_per_image % 4 == 0;
     for (int l = 0; l < P.nl; ++l)
         vec = vec && P.lvl[l].per_image.d % 4 == 0 && P.lvl[l].row_first % 4 == 0 && P.lvl[l].cell_first % 4 == 0;
-    if (P.conv) hipLaunchKernelGGL((k_yl_obj_fwd<false, true>), dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
+    if (P.conv && P.half) hipLaunchKernelGGL((k_yl_obj_fwd<false, true, _Float16>), dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws,
+                                             partial, (float*)(ws + W.off_dobj), obj_logits);
+    else if (P.conv) hipLaunchKernelGGL((k_yl_obj_fwd<false, true>), dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
                                    (float*)(ws + W.off_dobj), obj_logits);
     else if (vec) hipLaunchKernelGGL(k_yl_obj_fwd<true>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
                                 (float*)(ws + W.off_dobj), obj_logits);
@@ -582,7 +600,10 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
             if (v4) hipLaunchKernelGGL((k_yl_obj_bwd_conv<4, false>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, none_c);
             else hipLaunchKernelGGL((k_yl_obj_bwd_conv<1, false>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, none_c);
         }
-        if (P.cap > 0)
+        if (P.cap > 0 && P.half)
+            hipLaunchKernelGGL((k_yl_pos_bwd<true, _Float16>), dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
+                               (const long long*)idx, tbox, anch, (const long long*)tcls, counts, grad_loss);
+        else if (P.cap > 0)
             hipLaunchKernelGGL(k_yl_pos_bwd<true>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx,
                                tbox, anch, (const long long*)tcls, counts, grad_loss);
         return dh_launch_status();
@@ -614,7 +635,7 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
 
 }  // namespace
 
-static int loss_fwd(bool conv, const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+static int loss_fwd(int conv, const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                     const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
                     const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out,
                     void* workspace, size_t workspace_bytes, void* stream)
@@ -622,7 +643,8 @@ static int loss_fwd(bool conv, const float* const* p, const int* ny, const int* 
     yl_params P;
     yl_ws W;
     if (!p || !hyp || !out || !counts || !workspace) return DH_ERR_ARG;
-    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W, conv)) return DH_ERR_ARG;
+    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W, conv != 0)) return DH_ERR_ARG;
+    P.half = conv == 2;
     for (int l = 0; l < nl; ++l) if (!p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
@@ -635,7 +657,7 @@ extern "C" int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int*
                                 const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out,
                                 void* workspace, size_t workspace_bytes, void* stream)
 {
-    return loss_fwd(false, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, obj_logits, out, workspace,
+    return loss_fwd(0, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, obj_logits, out, workspace,
                     workspace_bytes, stream);
 }
 
@@ -644,11 +666,11 @@ extern "C" int dh_yolo_loss_fwd_conv(const float* const* conv, const int* ny, co
                                      const int* counts, int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace,
                                      size_t workspace_bytes, void* stream)
 {
-    return loss_fwd(true, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, nullptr, out, workspace,
+    return loss_fwd(1, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, nullptr, out, workspace,
                     workspace_bytes, stream);
 }
 
-static int loss_bwd(bool conv, const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+static int loss_bwd(int conv, const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                     const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
                     const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
                     float* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream)
@@ -656,7 +678,8 @@ static int loss_bwd(bool conv, const float* const* p, const int* ny, const int* 
     yl_params P;
     yl_ws W;
     if (!p || !grad_p || !hyp || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
-    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, P, W, conv)) return DH_ERR_ARG;
+    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, P, W, conv != 0)) return DH_ERR_ARG;
+    P.half = conv == 2;
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
@@ -668,7 +691,7 @@ extern "C" int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int*
                                 const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
                                 float* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream)
 {
-    return loss_bwd(false, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, grad_loss, grad_p, workspace,
+    return loss_bwd(0, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, grad_loss, grad_p, workspace,
                     workspace_bytes, stream);
 }
 
@@ -677,11 +700,11 @@ extern "C" int dh_yolo_loss_bwd_conv(const float* const* conv, const int* ny, co
                                      const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
                                      float* const* grad_conv, const void* workspace, size_t workspace_bytes, void* stream)
 {
-    return loss_bwd(true, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, grad_loss, grad_conv, workspace,
+    return loss_bwd(1, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp, grad_loss, grad_conv, workspace,
                     workspace_bytes, stream);
 }
 
-static int loss_fwd_bwd(bool conv, const float* targets, int64_t nt, const float* anchors, double anchor_t,
+static int loss_fwd_bwd(int conv, const float* targets, int64_t nt, const float* anchors, double anchor_t,
                         const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                         int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
                         const dh_yolo_hyp* hyp, const float* obj_logits, const float* grad_loss,
@@ -691,8 +714,9 @@ static int loss_fwd_bwd(bool conv, const float* targets, int64_t nt, const float
     yl_params P, Pb;
     yl_ws W, Wb;
     if (!p || !grad_p || !hyp || !out || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
-    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W, conv)) return DH_ERR_ARG;
-    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, Pb, Wb, conv)) return DH_ERR_ARG;
+    if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W, conv != 0)) return DH_ERR_ARG;
+    if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, Pb, Wb, conv != 0)) return DH_ERR_ARG;
+    P.half = Pb.half = conv == 2;
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
@@ -718,7 +742,7 @@ extern "C" int dh_yolo_loss_fwd_bwd(const float* targets, int64_t nt, const floa
                                     float* const* grad_p, float* out, void* assign_workspace, size_t assign_workspace_bytes,
                                     void* workspace, size_t workspace_bytes, void* stream)
 {
-    return loss_fwd_bwd(false, targets, nt, anchors, anchor_t, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp,
+    return loss_fwd_bwd(0, targets, nt, anchors, anchor_t, p, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp,
                         obj_logits, grad_loss, grad_p, out, assign_workspace, assign_workspace_bytes, workspace, workspace_bytes,
                         stream);
 }
@@ -730,9 +754,39 @@ extern "C" int dh_yolo_loss_fwd_bwd_conv(const float* targets, int64_t nt, const
                                          void* assign_workspace, size_t assign_workspace_bytes, void* workspace,
                                          size_t workspace_bytes, void* stream)
 {
-    return loss_fwd_bwd(true, targets, nt, anchors, anchor_t, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap,
+    return loss_fwd_bwd(1, targets, nt, anchors, anchor_t, conv, ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap,
                         hyp, nullptr, grad_loss, grad_conv, out, assign_workspace, assign_workspace_bytes, workspace,
                         workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_loss_fwd_conv_f16(const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                         const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                                         const int* counts, int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace,
+                                         size_t workspace_bytes, void* stream)
+{
+    return loss_fwd(2, reinterpret_cast<const float* const*>(conv), ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp,
+                    nullptr, out, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_loss_bwd_conv_f16(const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                         const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                                         const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
+                                         float* const* grad_conv, const void* workspace, size_t workspace_bytes, void* stream)
+{
+    return loss_bwd(2, reinterpret_cast<const float* const*>(conv), ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp,
+                    grad_loss, grad_conv, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_loss_fwd_bwd_conv_f16(const float* targets, int64_t nt, const float* anchors, double anchor_t,
+                                             const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                             int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
+                                             const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_conv, float* out,
+                                             void* assign_workspace, size_t assign_workspace_bytes, void* workspace,
+                                             size_t workspace_bytes, void* stream)
+{
+    return loss_fwd_bwd(2, targets, nt, anchors, anchor_t, reinterpret_cast<const float* const*>(conv), ny, nx, nl, bs, na, nc, idx,
+                        tbox, anch, tcls, counts, cap, hyp, nullptr, grad_loss, grad_conv, out, assign_workspace,
+                        assign_workspace_bytes, workspace, workspace_bytes, stream);
 }
 
 // The fused entry in two halves, for callers that can start the first one early: assignment and the positives' forward

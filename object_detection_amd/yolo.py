@@ -179,7 +179,7 @@ def head_maps(convs, na):
 
 def head_maps_decode(convs, na, anchors, stride, lazy=False):
     """Eval branch of Detect.forward after the convolutions (yolo.py:53-70): returns (decoded (bs, A, no), head maps).
-    lazy: the maps are returned as permuted views of the convolution outputs instead of being written (fp32 only).
+    lazy: the maps are returned as permuted views of the convolution outputs instead of being written.
     One launch reads the convolution outputs once and writes both; the results equal head_maps + detect_decode bit for bit.
     A half-precision head keeps fp16 maps; the decoded tensor is fp32, as detect_decode returns it for fp16 maps."""
     convs = [c.detach() for c in convs]
@@ -192,7 +192,6 @@ def head_maps_decode(convs, na, anchors, stride, lazy=False):
     dev = convs[0].device
     total = sum(na * h * w for h, w in zip(ny, nx))
     anchor_px, strides = _anchor_pixels(anchors, stride)
-    lazy = lazy and convs[0].dtype == torch.float32
     if lazy:
         maps = [c.view(bs, na, no, h, w).permute(0, 1, 3, 4, 2) for c, h, w in zip(convs, ny, nx)]
     else:

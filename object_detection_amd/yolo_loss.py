@@ -66,11 +66,13 @@ def conv_layout_of(p):
 
     Detect.forward with lazy_maps returns every map as the permuted VIEW x.view(bs,na,no,ny,nx).permute(0,1,3,4,2) of its
     convolution's output instead of the contiguous copy of yolo.py:54.  Such a view has the reference's shape and values; only
-    its strides tell.  When every p[i] is one (fp32, on the device), the result is the list of (bs, na*no, ny, nx) tensors
-    they are views of, which the loss kernels read -- and write the gradient for -- as they are."""
+    its strides tell.  When every p[i] is one (all fp32 or all fp16, on the device), the result is the list of
+    (bs, na*no, ny, nx) tensors they are views of, which the loss kernels read -- and write the gradient for -- as they are
+    (fp16 elements are widened on load; the gradient is fp32 and autograd converts it to the maps' type)."""
     convs = []
     for x in p:
-        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5) or x.is_contiguous():
+        if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 5 and x.dtype in (torch.float32, torch.float16)
+                and x.dtype == p[0].dtype) or x.is_contiguous():
             return None
         c = x.permute(0, 1, 4, 2, 3)
         if not c.is_contiguous():
@@ -112,8 +114,9 @@ def _loss_fwd(assign, hyp, nc, maps, conv_na=0):
     # when the inference decode has just read these very maps (validation: val.py:194-198 evaluates the loss on the
     # maps it decoded), it left a compact copy of their objectness logits; read that instead of the strided column
     if conv_na:
+        entry = lib.dh_yolo_loss_fwd_conv_f16 if maps[0].dtype == torch.float16 else lib.dh_yolo_loss_fwd_conv
         with L.device_guard(dev):
-            L.check(lib.dh_yolo_loss_fwd_conv(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
+            L.check(entry(ptrs, ny, nx, nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
                                               L.ptr(assign.anch), L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap,
                                               ctypes.byref(hyp), L.ptr(out), L.ptr(ws), ws_bytes, L.stream()),
                     "dh_yolo_loss_fwd_conv")
@@ -132,10 +135,12 @@ def _loss_bwd(assign, hyp, nc, maps, ws, g_loss, conv_na=0):
     (in the layout of `maps`: convolution layout when conv_na = na)."""
     nl = len(maps)
     bs, na = int(maps[0].shape[0]), conv_na or int(maps[0].shape[1])
-    grads = [torch.empty_like(x) for x in maps]
+    grads = [torch.empty_like(x, dtype=torch.float32) for x in maps]
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
-    entry = L.lib().dh_yolo_loss_bwd_conv if conv_na else L.lib().dh_yolo_loss_bwd
+    entry = L.lib().dh_yolo_loss_bwd
+    if conv_na:
+        entry = L.lib().dh_yolo_loss_bwd_conv_f16 if maps[0].dtype == torch.float16 else L.lib().dh_yolo_loss_bwd_conv
     with L.device_guard(maps[0].device):
         L.check(entry(ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc,
                                          L.ptr(assign.idx), L.ptr(assign.tbox), L.ptr(assign.anch),
@@ -174,12 +179,13 @@ def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss, co
         raise RuntimeError("ComputeLoss: unsupported problem size (a level exceeds 2^32 elements)")
     aws, ws = L.workspace(aws_bytes, dev), L.workspace(ws_bytes, dev)
     out = torch.empty(6 + nl, dtype=torch.float32, device=dev)
-    grads = [torch.empty_like(x) for x in maps]
+    grads = [torch.empty_like(x, dtype=torch.float32) for x in maps]
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
     if conv:
+        entry = lib.dh_yolo_loss_fwd_bwd_conv_f16 if maps[0].dtype == torch.float16 else lib.dh_yolo_loss_fwd_bwd_conv
         with L.device_guard(dev):
-            L.check(lib.dh_yolo_loss_fwd_bwd_conv(L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc,
+            L.check(entry(L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc,
                                                   L.ptr(A.idx), L.ptr(A.tbox), L.ptr(A.anch), L.ptr(A.tcls), L.ptr(A.counts),
                                                   A.cap, ctypes.byref(hyp), L.ptr(grad_loss), gptrs, L.ptr(out), L.ptr(aws),
                                                   aws_bytes, L.ptr(ws), ws_bytes, L.stream()), "dh_yolo_loss_fwd_bwd_conv")

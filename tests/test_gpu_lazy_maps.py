@@ -163,3 +163,35 @@ def test_detect_eval_with_lazy_maps():
         l1, i1 = crit(x1, targets)
     close(l1, l0, rtol=1e-6)
     close(i1, i0, rtol=1e-6)
+
+
+@pytest.mark.parametrize("bs,nc,shapes,nt,over", CASES[:4])
+def test_half_precision_lazy_maps_equal_the_fp32_loss_on_widened_maps(bs, nc, shapes, nt, over):
+    """Training under autocast (train.py:328-330) hands the loss fp16 maps.  As lazy views they are read as they are and
+    widened on load: loss and fp32 gradient equal the fp32 path on the maps converted with .float(); autograd then
+    converts the gradient to fp16 for the convolution."""
+    rs = np.random.RandomState(41)
+    hyp = dict(oy.HYP_SCRATCH)
+    hyp.update(over)
+    crit = make_loss(oy.grid_anchors(), nc, hyp)
+    targets = torch.from_numpy(synth_targets(rs, nt, bs, nc)).cuda()
+    base = [c.half() for c in _convs(rs, bs, 3, nc + 5, shapes)]
+
+    wide = [c.float().requires_grad_() for c in base]
+    loss_a, items_a = crit([v.contiguous() for v in _views(wide, 3)], targets)
+    loss_a.backward()
+
+    leaf = [c.clone().requires_grad_() for c in base]
+    loss_b, items_b = crit(_views(leaf, 3), targets)
+    loss_b.backward()
+    close(loss_b, loss_a, rtol=1e-6)
+    close(items_b, items_a, rtol=1e-6)
+    for a, b in zip(wide, leaf):
+        assert b.grad.dtype == torch.float16 and b.grad.is_contiguous()
+        close(b.grad.float(), a.grad.half().float(), rtol=2e-3, floor=1e-6)
+
+    _, _, grads = crit.forward_backward(_views(base, 3), targets)
+    for a, g in zip(wide, grads):
+        assert g.dtype == torch.float32
+        # cells with three or more assigned rows add their terms in a different order (fp32 atomics)
+        close(g.permute(0, 1, 4, 2, 3).reshape(a.grad.shape), a.grad, rtol=1e-5, floor=1e-8)
