@@ -133,6 +133,20 @@ rows += [
     ("train head: head_maps + loss + backward", lambda: train_head(lambda cs: yolo.head_maps(cs, na)), 5 * elems * 4),
     ("train head: lazy maps + loss + backward", lambda: train_head(lazy), elems * 4),
 ]
+# the same under autocast (train.py:328-330): the convolution outputs, and so the maps, are fp16
+h_leaves = [c.half().requires_grad_() for c in convs]
+
+
+def train_head_h(make_maps):
+    loss, _ = crit(make_maps(h_leaves), targets)
+    return [g.contiguous() for g in torch.autograd.grad(loss, h_leaves)]
+
+
+rows += [
+    ("fp16 train head: torch permute copy + loss + backward", lambda: train_head_h(lambda cs: [v.contiguous() for v in lazy(cs)]), elems * 10),
+    ("fp16 train head: head_maps + loss + backward", lambda: train_head_h(lambda cs: yolo.head_maps(cs, na)), elems * 10),
+    ("fp16 train head: lazy maps + loss + backward", lambda: train_head_h(lazy), elems * 6),
+]
 for name, fn, nbytes in rows:
     ms = timed(fn)
     print(f"{name:42s} {ms * 1e3:8.1f} us   {nbytes / ms / 1e6:8.1f} GB/s of its own algorithmic bytes", flush=True)
