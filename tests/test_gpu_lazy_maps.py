@@ -68,7 +68,7 @@ def test_loss_on_lazy_maps_equals_loss_on_contiguous_maps(bs, nc, shapes, nt, ov
     close(items_b, items_a, rtol=1e-6)
     for ga, gb in zip(a, b):
         assert gb.grad.is_contiguous() and gb.grad.shape == ga.grad.shape
-        close(gb.grad, ga.grad, rtol=1e-6, floor=1e-9)
+        close(gb.grad, ga.grad, rtol=1e-5, floor=1e-7)
         # everything but cells with three or more assigned rows (fp32 add order) is the same float
         assert float((gb.grad != ga.grad).float().mean()) < 2e-3
 
@@ -80,7 +80,7 @@ def test_loss_on_lazy_maps_equals_loss_on_contiguous_maps(bs, nc, shapes, nt, ov
         assert gc.shape == (bs, 3, c.shape[2], c.shape[3], nc + 5)
         back = gc.permute(0, 1, 4, 2, 3)
         assert back.is_contiguous()
-        close(back.reshape(ga.grad.shape), ga.grad, rtol=1e-6, floor=1e-9)
+        close(back.reshape(ga.grad.shape), ga.grad, rtol=1e-5, floor=1e-7)
 
 
 def test_lazy_maps_against_the_oracle():
@@ -194,4 +194,4 @@ def test_half_precision_lazy_maps_equal_the_fp32_loss_on_widened_maps(bs, nc, sh
     for a, g in zip(wide, grads):
         assert g.dtype == torch.float32
         # cells with three or more assigned rows add their terms in a different order (fp32 atomics)
-        close(g.permute(0, 1, 4, 2, 3).reshape(a.grad.shape), a.grad, rtol=1e-5, floor=1e-8)
+        close(g.permute(0, 1, 4, 2, 3).reshape(a.grad.shape), a.grad, rtol=1e-5, floor=1e-7)
