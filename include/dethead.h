@@ -263,21 +263,25 @@ int dh_yolo_loss_fwd_bwd_conv(const float* targets, int64_t nt, const float* anc
                               const float* grad_loss, float* const* grad_conv, float* out, void* assign_workspace,
                               size_t assign_workspace_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* The same three for a head that runs in half precision (training under autocast, object_detection/yolov5/train.py:328-330:
- * the convolution outputs are fp16): conv[l] holds fp16 elements, which are widened on load; the arithmetic, out and
- * grad_conv stay fp32, so every result equals the fp32 entry on the outputs converted with .float(). */
+ * the convolution outputs are fp16): conv[l] holds fp16 elements, which are widened on load; the arithmetic and out stay
+ * fp32, so the forward equals the fp32 entry on the outputs converted with .float().
+ * grad_f16 == 0: grad_conv[l] are fp32 tensors and equal the fp32 entry's gradient.
+ * grad_f16 != 0: grad_conv[l] are fp16 tensors, the type autograd hands back to an fp16 convolution: an element that
+ * receives one term is that term rounded to fp16; a cell assigned to several target rows accumulates their terms with the
+ * hardware's packed fp16 atomic add (one rounding per term). */
 int dh_yolo_loss_fwd_conv_f16(const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                               const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
                               int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace, size_t workspace_bytes,
                               void* stream);
 int dh_yolo_loss_bwd_conv_f16(const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                               const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
-                              int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_conv,
+                              int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss, int grad_f16, void* const* grad_conv,
                               const void* workspace, size_t workspace_bytes, void* stream);
 int dh_yolo_loss_fwd_bwd_conv_f16(const float* targets, int64_t nt, const float* anchors, double anchor_t,
                                   const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                                   int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
-                                  const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_conv, float* out,
-                                  void* assign_workspace, size_t assign_workspace_bytes, void* workspace,
+                                  const dh_yolo_hyp* hyp, const float* grad_loss, int grad_f16, void* const* grad_conv,
+                                  float* out, void* assign_workspace, size_t assign_workspace_bytes, void* workspace,
                                   size_t workspace_bytes, void* stream);
 /* dh_yolo_loss_fwd_bwd in two halves, for callers that can start the first one early.  dh_yolo_loss_positives: target
  * assignment (loss.py:169-222) and the forward of the assigned rows (loss.py:126-150) -- they read only the targets and

@@ -84,10 +84,10 @@ SIGNATURES = {
     "dh_yolo_loss_fwd_conv_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_loss_bwd_conv_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                          c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_loss_fwd_bwd_conv_f16": (c_int, [c_void_p, c_i64, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p,
-                                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+                                              c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_loss_positives": (c_int, [c_void_p, c_i64, c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_size_t,
                                        c_void_p, c_size_t, c_void_p]),

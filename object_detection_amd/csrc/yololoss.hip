@@ -43,7 +43,8 @@ struct yl_level {
 struct yl_params {
     yl_level lvl[DH_MAX_LEVELS];
     int nl, bs, na, nc, no;
-    int half;                  // convolution layout only: the tensors hold fp16 elements (the gradient stays fp32)
+    int half;                  // convolution layout only: the tensors hold fp16 elements
+    int half_grad;             // ... and the gradient is written in fp16 too (else fp32)
     int conv;                  // 0: maps (bs, na, ny, nx, no); 1: convolution layout (bs, na*no, ny, nx)
     uint32_t rows_per_image;   // A = sum over levels of na*ny*nx
     long cap;
@@ -89,6 +90,20 @@ template <typename T> __device__ __forceinline__ float ld_el(const float* base, 
 template <typename T> __device__ __forceinline__ float ld_el_nt(const float* base, size_t k)
 {
     return (float)__builtin_nontemporal_load(reinterpret_cast<const T*>(base) + k);
+}
+
+// gradient element k of a tensor of fp32 or fp16 elements += v.  fp16: the hardware's packed add on the aligned pair that
+// holds the element (the other half adds zero); every add rounds to fp16
+typedef _Float16 dh_h2v __attribute__((ext_vector_type(2)));
+typedef _Float16 dh_h4v __attribute__((ext_vector_type(4)));
+template <typename G> __device__ __forceinline__ void add_el(float* base, size_t k, float v);
+template <> __device__ __forceinline__ void add_el<float>(float* base, size_t k, float v) { atomicAdd(base + k, v); }
+template <> __device__ __forceinline__ void add_el<_Float16>(float* base, size_t k, float v)
+{
+    _Float16* h = reinterpret_cast<_Float16*>(base);
+    const _Float16 hv = (_Float16)v, zero = (_Float16)0.0f;
+    const dh_h2v pair = (k & 1) ? dh_h2v{zero, hv} : dh_h2v{hv, zero};
+    __builtin_amdgcn_global_atomic_fadd_v2f16(reinterpret_cast<dh_h2v*>(h + (k & ~(size_t)1)), pair);
 }
 
 struct pos_row {
@@ -372,7 +387,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const flo
 // The dense pass for the convolution layout: per (image, anchor) a span of no planes of ny*nx elements, all zero except
 // plane 4, which is the stored objectness derivative times the level's scale.  A workgroup owns 256 vectors of one span,
 // so whether a vector lies in the objectness plane is a range test (ny*nx % VEC == 0: no vector straddles planes).
-template <int VEC, bool FINAL>
+template <int VEC, bool FINAL, typename G = float>
 __global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, const float* __restrict__ dobj,
                                                          const float* __restrict__ g_loss, const yl_final_args F)
 {
@@ -398,17 +413,22 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, cons
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o[k] = scale * d[k];
     }
-    float* __restrict__ g = L.g + (size_t)ba * span + e;
+    G* __restrict__ g = reinterpret_cast<G*>(L.g) + (size_t)ba * span + e;
     if (VEC == 4) {
-        const dh_f4 ov = {o[0], o[1], o[2], o[3]};
-        __builtin_nontemporal_store(ov, reinterpret_cast<dh_f4*>(g));
+        if (sizeof(G) == 4) {
+            const dh_f4 ov = {o[0], o[1], o[2], o[3]};
+            __builtin_nontemporal_store(ov, reinterpret_cast<dh_f4*>(g));
+        } else {
+            const dh_h4v ov = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+            __builtin_nontemporal_store(ov, reinterpret_cast<dh_h4v*>(g));
+        }
     } else {
-        g[0] = o[0];
+        g[0] = (G)o[0];
     }
 }
 
 // ------------------------------------------------------------------------------------ backward: positives
-template <bool CONV, typename T = float>
+template <bool CONV, typename T = float, typename G = float>
 __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
                                                     const long long* __restrict__ tcls, const int* __restrict__ counts,
@@ -424,7 +444,8 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
     if (!R.ok) return;
     const float* __restrict__ ps = L.p + (sizeof(T) == 4 ? R.off : 0);
     const size_t e0 = sizeof(T) == 4 ? 0 : R.off;
-    float* __restrict__ gs = L.g + R.off;       // the gradient is fp32 whatever the maps hold
+    float* __restrict__ gs = L.g + (sizeof(G) == 4 ? R.off : 0);      // fp16 gradient: add_el applies element offsets
+    const size_t g0 = sizeof(G) == 4 ? 0 : R.off;
     const size_t cs = CONV ? R.cs : 1;
     const float up = g_loss[0] * (float)P.bs;
     if (lane < 4) {
@@ -443,12 +464,12 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
         else if (lane == 1) g = gy * 2.0f * s1 * (1.0f - s1);
         else if (lane == 2) g = gw * (2.0f * tw * R.an[0]) * (2.0f * s2 * (1.0f - s2));
         else g = gh * (2.0f * th * R.an[1]) * (2.0f * s3 * (1.0f - s3));
-        atomicAdd(gs + lane * cs, g);       // duplicates of one cell accumulate, as index_put(accumulate) does
+        add_el<G>(gs, g0 + lane * cs, g);   // duplicates of one cell accumulate, as index_put(accumulate) does
     }
     if (P.nc > 1) {
         const float sc = up * P.cls / ((float)n * (float)P.nc);
         for (int c = lane; c < P.nc; c += 64)
-            atomicAdd(gs + (5 + c) * cs, sc * bce_grad(ld_el<T>(ps, e0 + (5 + c) * cs), c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma));
+            add_el<G>(gs, g0 + (5 + c) * cs, sc * bce_grad(ld_el<T>(ps, e0 + (5 + c) * cs), c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma));
     }
 }
 
@@ -467,6 +488,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
     P.nl = nl; P.bs = bs; P.na = na; P.nc = nc; P.no = nc + 5; P.cap = cap;
     P.conv = conv ? 1 : 0;
     P.half = 0;
+    P.half_grad = 0;
     if (hyp) {
         P.box = hyp->box; P.obj = hyp->obj; P.cls = hyp->cls; P.cls_pw = hyp->cls_pw; P.obj_pw = hyp->obj_pw;
         P.gamma = hyp->fl_gamma; P.cp = hyp->cp; P.cn = hyp->cn; P.gr = hyp->gr;
@@ -593,6 +615,19 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
         const float* dobj_c = (const float*)(ws + W.off_dobj);
         const yl_final_args none_c = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         const dim3 grid_c(sum_blocks(P));
+        if (P.half_grad) {
+            if (F) {
+                if (v4) hipLaunchKernelGGL((k_yl_obj_bwd_conv<4, true, _Float16>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, *F);
+                else hipLaunchKernelGGL((k_yl_obj_bwd_conv<1, true, _Float16>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, *F);
+            } else {
+                if (v4) hipLaunchKernelGGL((k_yl_obj_bwd_conv<4, false, _Float16>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, none_c);
+                else hipLaunchKernelGGL((k_yl_obj_bwd_conv<1, false, _Float16>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, none_c);
+            }
+            if (P.cap > 0)
+                hipLaunchKernelGGL((k_yl_pos_bwd<true, _Float16, _Float16>), dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
+                                   (const long long*)idx, tbox, anch, (const long long*)tcls, counts, grad_loss);
+            return dh_launch_status();
+        }
         if (F) {
             if (v4) hipLaunchKernelGGL((k_yl_obj_bwd_conv<4, true>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, *F);
             else hipLaunchKernelGGL((k_yl_obj_bwd_conv<1, true>), grid_c, dim3(256), 0, st, P, dobj_c, grad_loss, *F);
@@ -644,7 +679,7 @@ static int loss_fwd(int conv, const float* const* p, const int* ny, const int* n
     yl_ws W;
     if (!p || !hyp || !out || !counts || !workspace) return DH_ERR_ARG;
     if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W, conv != 0)) return DH_ERR_ARG;
-    P.half = conv == 2;
+    P.half = conv >= 2;
     for (int l = 0; l < nl; ++l) if (!p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
@@ -679,7 +714,8 @@ static int loss_bwd(int conv, const float* const* p, const int* ny, const int* n
     yl_ws W;
     if (!p || !grad_p || !hyp || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
     if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, P, W, conv != 0)) return DH_ERR_ARG;
-    P.half = conv == 2;
+    P.half = conv >= 2;
+    P.half_grad = conv == 3;
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
@@ -716,7 +752,8 @@ static int loss_fwd_bwd(int conv, const float* targets, int64_t nt, const float*
     if (!p || !grad_p || !hyp || !out || !grad_loss || !counts || !workspace) return DH_ERR_ARG;
     if (!make_params(p, nullptr, ny, nx, nl, bs, na, nc, (long)cap, hyp, false, P, W, conv != 0)) return DH_ERR_ARG;
     if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, Pb, Wb, conv != 0)) return DH_ERR_ARG;
-    P.half = Pb.half = conv == 2;
+    P.half = Pb.half = conv >= 2;
+    Pb.half_grad = conv == 3;
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
@@ -771,22 +808,23 @@ extern "C" int dh_yolo_loss_fwd_conv_f16(const void* const* conv, const int* ny,
 extern "C" int dh_yolo_loss_bwd_conv_f16(const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                                          const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
                                          const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
-                                         float* const* grad_conv, const void* workspace, size_t workspace_bytes, void* stream)
+                                         int grad_f16, void* const* grad_conv, const void* workspace, size_t workspace_bytes,
+                                         void* stream)
 {
-    return loss_bwd(2, reinterpret_cast<const float* const*>(conv), ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp,
-                    grad_loss, grad_conv, workspace, workspace_bytes, stream);
+    return loss_bwd(grad_f16 ? 3 : 2, reinterpret_cast<const float* const*>(conv), ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp,
+                    grad_loss, reinterpret_cast<float* const*>(grad_conv), workspace, workspace_bytes, stream);
 }
 
 extern "C" int dh_yolo_loss_fwd_bwd_conv_f16(const float* targets, int64_t nt, const float* anchors, double anchor_t,
                                              const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                                              int64_t* idx, float* tbox, float* anch, int64_t* tcls, int* counts, int64_t cap,
-                                             const dh_yolo_hyp* hyp, const float* grad_loss, float* const* grad_conv, float* out,
-                                             void* assign_workspace, size_t assign_workspace_bytes, void* workspace,
+                                             const dh_yolo_hyp* hyp, const float* grad_loss, int grad_f16, void* const* grad_conv,
+                                             float* out, void* assign_workspace, size_t assign_workspace_bytes, void* workspace,
                                              size_t workspace_bytes, void* stream)
 {
-    return loss_fwd_bwd(2, targets, nt, anchors, anchor_t, reinterpret_cast<const float* const*>(conv), ny, nx, nl, bs, na, nc, idx,
-                        tbox, anch, tcls, counts, cap, hyp, nullptr, grad_loss, grad_conv, out, assign_workspace,
-                        assign_workspace_bytes, workspace, workspace_bytes, stream);
+    return loss_fwd_bwd(grad_f16 ? 3 : 2, targets, nt, anchors, anchor_t, reinterpret_cast<const float* const*>(conv), ny, nx, nl, bs, na, nc, idx,
+                        tbox, anch, tcls, counts, cap, hyp, nullptr, grad_loss, reinterpret_cast<float* const*>(grad_conv), out,
+                        assign_workspace, assign_workspace_bytes, workspace, workspace_bytes, stream);
 }
 
 // The fused entry in two halves, for callers that can start the first one early: assignment and the positives' forward

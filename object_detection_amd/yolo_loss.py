@@ -132,20 +132,24 @@ def _loss_fwd(assign, hyp, nc, maps, conv_na=0):
 
 def _loss_bwd(assign, hyp, nc, maps, ws, g_loss, conv_na=0):
     """Launch the backward kernels for upstream gradient g_loss (1 float on the device); returns grads
-    (in the layout of `maps`: convolution layout when conv_na = na)."""
+    (in the layout of `maps`: convolution layout when conv_na = na, and then in the maps' element type: fp16 convolution
+    outputs get the fp16 gradient their convolution's backward takes)."""
     nl = len(maps)
     bs, na = int(maps[0].shape[0]), conv_na or int(maps[0].shape[1])
-    grads = [torch.empty_like(x, dtype=torch.float32) for x in maps]
+    half = bool(conv_na) and maps[0].dtype == torch.float16
+    grads = [torch.empty_like(x, dtype=torch.float16 if half else torch.float32) for x in maps]
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
-    entry = L.lib().dh_yolo_loss_bwd
-    if conv_na:
-        entry = L.lib().dh_yolo_loss_bwd_conv_f16 if maps[0].dtype == torch.float16 else L.lib().dh_yolo_loss_bwd_conv
+    head = (ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc, L.ptr(assign.idx), L.ptr(assign.tbox),
+            L.ptr(assign.anch), L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap, ctypes.byref(hyp), L.ptr(g_loss))
+    tail = (gptrs, L.ptr(ws), ws.numel(), L.stream())
     with L.device_guard(maps[0].device):
-        L.check(entry(ptrs, L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc,
-                                         L.ptr(assign.idx), L.ptr(assign.tbox), L.ptr(assign.anch),
-                                         L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap, ctypes.byref(hyp),
-                                         L.ptr(g_loss), gptrs, L.ptr(ws), ws.numel(), L.stream()), "dh_yolo_loss_bwd")
+        if half:
+            L.check(L.lib().dh_yolo_loss_bwd_conv_f16(*head, 1, *tail), "dh_yolo_loss_bwd_conv_f16")
+        elif conv_na:
+            L.check(L.lib().dh_yolo_loss_bwd_conv(*head, *tail), "dh_yolo_loss_bwd_conv")
+        else:
+            L.check(L.lib().dh_yolo_loss_bwd(*head, *tail), "dh_yolo_loss_bwd")
     return grads
 
 
@@ -183,12 +187,14 @@ def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss, co
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
     if conv:
-        entry = lib.dh_yolo_loss_fwd_bwd_conv_f16 if maps[0].dtype == torch.float16 else lib.dh_yolo_loss_fwd_bwd_conv
+        head = (L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc, L.ptr(A.idx), L.ptr(A.tbox),
+                L.ptr(A.anch), L.ptr(A.tcls), L.ptr(A.counts), A.cap, ctypes.byref(hyp), L.ptr(grad_loss))
+        tail = (gptrs, L.ptr(out), L.ptr(aws), aws_bytes, L.ptr(ws), ws_bytes, L.stream())
         with L.device_guard(dev):
-            L.check(entry(L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc,
-                                                  L.ptr(A.idx), L.ptr(A.tbox), L.ptr(A.anch), L.ptr(A.tcls), L.ptr(A.counts),
-                                                  A.cap, ctypes.byref(hyp), L.ptr(grad_loss), gptrs, L.ptr(out), L.ptr(aws),
-                                                  aws_bytes, L.ptr(ws), ws_bytes, L.stream()), "dh_yolo_loss_fwd_bwd_conv")
+            if maps[0].dtype == torch.float16:      # fp32 gradients: the caller takes them as they are
+                L.check(lib.dh_yolo_loss_fwd_bwd_conv_f16(*head, 0, *tail), "dh_yolo_loss_fwd_bwd_conv_f16")
+            else:
+                L.check(lib.dh_yolo_loss_fwd_bwd_conv(*head, *tail), "dh_yolo_loss_fwd_bwd_conv")
         return A, out, grads
     logits = objectness_logits(maps)
     with L.device_guard(dev):

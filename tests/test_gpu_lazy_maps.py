@@ -188,7 +188,11 @@ def test_half_precision_lazy_maps_equal_the_fp32_loss_on_widened_maps(bs, nc, sh
     close(items_b, items_a, rtol=1e-6)
     for a, b in zip(wide, leaf):
         assert b.grad.dtype == torch.float16 and b.grad.is_contiguous()
-        close(b.grad.float(), a.grad.half().float(), rtol=2e-3, floor=1e-6)
+        # one fp16 rounding per term: exact rounding of the fp32 gradient where a cell has one assigned row, a few fp16
+        # ulps where several rows share it
+        close(b.grad.float(), a.grad.half().float(), rtol=4e-3, floor=2e-3)
+        single = (a.grad != 0) & (b.grad.float() == a.grad.half().float())
+        assert float(single.sum()) > 0.7 * float((a.grad != 0).sum())
 
     _, _, grads = crit.forward_backward(_views(base, 3), targets)
     for a, g in zip(wide, grads):
