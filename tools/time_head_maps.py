@@ -61,6 +61,7 @@ rows = [
     ("detect_decode alone", lambda: yolo.detect_decode(maps, anchors, stride), 2 * elems * 4),
     ("head_maps (layout change only)", lambda: yolo.head_maps(convs, na), 2 * elems * 4),
     ("head_maps_decode (fused)", lambda: yolo.head_maps_decode(convs, na, anchors, stride), 3 * elems * 4),
+    ("head_maps_decode, lazy maps (decoded tensor only)", lambda: yolo.head_maps_decode(convs, na, anchors, stride, lazy=True), 2 * elems * 4),
     ("torch backward copy", torch_bwd, 2 * elems * 4),
     ("head_maps backward", ours_bwd, 2 * elems * 4),
 ]
