@@ -34,6 +34,7 @@ struct yl_level {
     long cell_first;     // offset of this level in the owner map
     dh_fastdiv per_image;   // na*ny*nx
     dh_fastdiv plane;       // ny*nx
+    dh_fastdiv gchunks;     // convolution-layout dense gradient: workgroups per (image, anchor) span
     uint32_t row_first;  // first row of this level inside one image of the decoded (bs, A) planes
     unsigned blocks;     // dense-pass blocks of this level (forward: objectness blocks, backward: gradient blocks)
     unsigned fwd_blocks; // objectness-pass blocks of this level: one partial sum each
@@ -400,9 +401,8 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, cons
     const yl_level& L = P.lvl[l];
     const uint32_t hw = L.plane.d;
     const uint32_t span = (uint32_t)P.no * hw;
-    const uint32_t chunks = (span / VEC + 255) / 256;
-    const uint32_t ba = blk / chunks;
-    const uint32_t e = ((blk - ba * chunks) * 256 + threadIdx.x) * VEC;
+    const uint32_t ba = dh_div(blk, L.gchunks);
+    const uint32_t e = ((blk - ba * L.gchunks.d) * 256 + threadIdx.x) * VEC;
     if (e >= span) return;
     const float scale = g_loss[0] * (float)P.bs * P.obj * L.balance / (float)L.cells;
     float o[VEC];
@@ -501,6 +501,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
         yl_level& L = P.lvl[l];
         L.per_image = dh_make_fastdiv((uint32_t)(na * ny[l] * nx[l]));
         L.plane = dh_make_fastdiv((uint32_t)(ny[l] * nx[l]));
+        L.gchunks = dh_make_fastdiv(1);
         L.row_first = row_first;
         row_first += (uint32_t)(na * ny[l] * nx[l]);
         L.p = p ? p[l] : nullptr;
@@ -610,7 +611,9 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
         v4 = v4 && ((reinterpret_cast<uintptr_t>(ws) + W.off_dobj) & 15u) == 0;
         for (int l = 0; l < P.nl; ++l) {
             const uint32_t span = (uint32_t)P.no * P.lvl[l].plane.d;
-            P.lvl[l].blocks = (unsigned)((size_t)P.bs * P.na * ((span / (v4 ? 4 : 1) + 255) / 256));
+            const uint32_t chunks = (span / (v4 ? 4 : 1) + 255) / 256;
+            P.lvl[l].gchunks = dh_make_fastdiv(chunks);
+            P.lvl[l].blocks = (unsigned)((size_t)P.bs * P.na * chunks);
         }
         const float* dobj_c = (const float*)(ws + W.off_dobj);
         const yl_final_args none_c = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
