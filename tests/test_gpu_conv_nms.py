@@ -131,3 +131,17 @@ def test_conv_nms_when_every_class_of_every_position_passes(half):
     want = non_max_suppression(dec, **kw)
     same(conv_nms(convs, 3, anchors, stride, **kw), want)
     assert all(int(w.shape[0]) == 300 for w in want)
+
+
+def test_conv_nms_inference_sweep_shape():
+    """One GPU's share of the 1280 px sweep (16 images, 100 800 anchors each) at validation thresholds."""
+    from object_detection_amd.general import conv_nms, non_max_suppression
+    from object_detection_amd.yolo import head_maps_decode
+    convs = _head(5, 16, 1280, 80, frac=0.001)
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    dec, _ = head_maps_decode(convs, 3, anchors, stride)
+    assert dec.shape == (16, 100800, 85)
+    kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    want = non_max_suppression(dec, **kw)
+    same(conv_nms(convs, 3, anchors, stride, **kw), want)
+    assert sum(int(w.shape[0]) for w in want) > 16 * 100
