@@ -414,9 +414,11 @@ struct conv_blocks {
 };
 
 // one key per passing lane: into the workgroup's stage, or straight into the image's list when the stage is full.
-// Called by whole waves.  s_n only ever counts keys that are in the stage: a wave that finds no room takes its
-// reservation back, and while it has not, every other wave sees a count beyond the capacity and goes direct too.
-__device__ __forceinline__ void conv_emit(bool pass, u64 key, u64* stage, int* s_n, u64* __restrict__ out, int* counter, int cap)
+// Called by whole waves.  s_n only grows: a reservation that does not fit the stage is never handed back (a later,
+// smaller one could otherwise land beyond keys that were never written), it lowers s_valid to where it started, and
+// since every reservation after it starts beyond the capacity as well, the staged keys are exactly [0, s_valid).
+__device__ __forceinline__ void conv_emit(bool pass, u64 key, u64* stage, int* s_n, int* s_valid, u64* __restrict__ out, int* counter,
+                                          int cap)
 {
     const u64 pm = __ballot(pass);
     if (!pm) return;
@@ -425,7 +427,7 @@ __device__ __forceinline__ void conv_emit(bool pass, u64 key, u64* stage, int* s
     if (lane == 0) {
         first = atomicAdd(s_n, cnt);
         if (first + cnt > CONV_STAGE) {
-            atomicSub(s_n, cnt);
+            atomicMin(s_valid, first);
             first = atomicAdd(counter, cnt);
             direct = 1;
         }
@@ -444,7 +446,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
                                                             u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
 {
     __shared__ u64 stage[CONV_STAGE];
-    __shared__ int s_n, s_base;
+    __shared__ int s_n, s_valid, s_base;
     const int b = blockIdx.y;
     uint32_t blk = blockIdx.x;
     int l = 0;
@@ -462,7 +464,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
     const T* __restrict__ plane0 = reinterpret_cast<const T*>(L.src) + (size_t)b * L.elems + (size_t)a * S.no * hw;
     const uint32_t row_wave = L.row_first + a * hw + s_wave;          // row of the decoded tensor (yolo.py:68,70)
     u64* __restrict__ out = keys + (size_t)b * cap_pad;
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) { s_n = 0; s_valid = CONV_STAGE; }
     __syncthreads();
     float obj = 0.0f;
     if (s < hw) obj = dh_sigmoid(ldf_nt(plane0 + 4 * (size_t)hw + s));
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
                     if (class_keep != nullptr && class_keep[c] == 0) continue;                              // general.py:705
                     const float sc = dh_sigmoid(v[u]) * obj;          // yolo.py:62, general.py:691
                     conv_emit(cand && sc > conf, ((u64)score_key(sc) << 32) | (uint32_t)((row_wave + lane) * nc + c), stage,
-                              &s_n, out, &counts[b], cap);            // general.py:698
+                              &s_n, &s_valid, out, &counts[b], cap);  // general.py:698
                 } else {
                     const float sc = dh_sigmoid(v[u]) * obj;
                     if (cand && sc > best) {                          // general.py:701 (first maximum)
@@ -540,8 +542,8 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
                         const float sc = dh_sigmoid(x[k][h]) * o[k];  // yolo.py:62, general.py:691
                         if (MULTI) {
                             conv_emit(k < nr && keepc && sc > conf,
-                                      ((u64)score_key(sc) << 32) | (uint32_t)((row_wave + r[k]) * nc + c), stage, &s_n, out,
-                                      &counts[b], cap);
+                                      ((u64)score_key(sc) << 32) | (uint32_t)((row_wave + r[k]) * nc + c), stage, &s_n,
+                                      &s_valid, out, &counts[b], cap);
                         } else if (c < nc && sc > bv[k]) {
                             bv[k] = sc;
                             bc[k] = c;
@@ -560,11 +562,11 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
     }
     if (!MULTI) {
         const bool pass = cand && best > conf && (class_keep == nullptr || class_keep[best_c] != 0);   // general.py:702,705
-        conv_emit(pass, ((u64)score_key(best) << 32) | (uint32_t)((row_wave + lane) * nc + best_c), stage, &s_n, out, &counts[b],
-                  cap);
+        conv_emit(pass, ((u64)score_key(best) << 32) | (uint32_t)((row_wave + lane) * nc + best_c), stage, &s_n, &s_valid, out,
+                  &counts[b], cap);
     }
     __syncthreads();
-    const int n = s_n;
+    const int n = min(s_n, s_valid);                                  // the staged keys (see conv_emit)
     if (n == 0) return;                                               // workgroup-uniform
     if (threadIdx.x == 0) s_base = atomicAdd(&counts[b], n);
     __syncthreads();
@@ -959,8 +961,9 @@ __global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, d
     if (r < m) {
         const u64 key = keys[(size_t)b * cap_pad + r];
         const uint32_t ord = (uint32_t)key;
-        const uint32_t anchor = dh_div(ord, ncd);
+        uint32_t anchor = dh_div(ord, ncd);
         const uint32_t cls = ord - anchor * ncd.d;
+        if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;      // a key always names a row of the image: never address beyond it
         float x, y, w, h;
         if (RAW) {
             const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
@@ -1253,8 +1256,9 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
     const int no = (int)ncd.d + 5;
     if ((int)threadIdx.x < n) {
         const uint32_t ord = (uint32_t)s_key[threadIdx.x];
-        const uint32_t anchor = dh_div(ord, ncd);
+        uint32_t anchor = dh_div(ord, ncd);
         const uint32_t cls = ord - anchor * ncd.d;
+        if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;      // a key always names a row of the image: never address beyond it
         float x, y, w, h;
         if (RAW) {
             const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);

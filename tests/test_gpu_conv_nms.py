@@ -145,3 +145,30 @@ def test_conv_nms_inference_sweep_shape():
     want = non_max_suppression(dec, **kw)
     same(conv_nms(convs, 3, anchors, stride, **kw), want)
     assert sum(int(w.shape[0]) for w in want) > 16 * 100
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_conv_nms_stage_overflow_with_mixed_ballot_counts(seed):
+    """Every position is a candidate and about one class in nine passes, so a 256-position workgroup emits 2 000-4 000
+    keys in ballots of 1-20 lanes: its 2 048-key LDS stage fills up in the middle of the class walk with reservations of
+    many different sizes in flight.  A large max_det and a high IoU threshold put thousands of rows per image into
+    the comparison, so a lost or invented key shows."""
+    from object_detection_amd.general import conv_nms, non_max_suppression
+    from object_detection_amd.yolo import head_maps_decode
+    rs = np.random.RandomState(seed)
+    bs, nc = 2, 80
+    convs = []
+    for n in (32, 16, 8):
+        x = rs.normal(0, 1.0, (bs, 3, nc + 5, n, n)).astype(np.float32)
+        x[:, :, 4] += 5.0                                    # every position is a candidate
+        x[:, :, 5:] -= 2.3                                   # P(sigmoid(x) * obj > 0.25) ~ 0.11 per class
+        x[:, :, 2:4] *= 0.2
+        convs.append(torch.from_numpy(x.reshape(bs, 3 * (nc + 5), n, n)).cuda())
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    kw = dict(conf_thres=0.25, iou_thres=0.9, multi_label=True, max_det=4000)
+    dec, _ = head_maps_decode(convs, 3, anchors, stride)
+    per_tile = (dec[0, :256, 5:] * dec[0, :256, 4:5] > 0.25).sum().item()
+    assert 2048 < per_tile < 4500, per_tile                  # the first workgroup alone overflows its stage
+    want = non_max_suppression(dec, **kw)
+    same(conv_nms(convs, 3, anchors, stride, **kw), want)
+    assert all(int(w.shape[0]) > 2000 for w in want)
