@@ -14,6 +14,8 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -127,12 +129,54 @@ def cpu_baseline(seconds_budget=12.0):
                       f"(PyTorch-CPU restatement + C greedy NMS), {dt * 1e3:.1f} ms/step"}
 
 
+PMC_FILES = ("r2_pmc_traffic.json", "r1_pmc_traffic.json")      # newest first
+
+
 def load_pmc_traffic():
-    path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f)
-    return {}
+    """The committed counter summary of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes and the
+    --kernel-trace --stats averages): (contents, path relative to the repository)."""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f), "profiles/" + name
+    return {}, None
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL backend), wait
+    for them and exit with their status.  This process never touches the GPU (counting devices does not initialise
+    it), so nothing that has is ever replaced or forked."""
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("DH_BENCH_SHARE_DEVICE"):
+        raise SystemExit(f"bench.py --gpus {n} needs {n} devices, this machine shows {have}")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in pending:      # one rank failed: the others would wait in a collective forever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    raise SystemExit(rc)
 
 
 def main():
@@ -150,7 +194,16 @@ def main():
     ap.add_argument("--autograd", action="store_true",
                     help="call loss = crit(p, t); autograd.grad(loss, p) instead of crit.forward_backward(p, t): same kernels, "
                          "plus the autograd engine's hop to its device thread and back (two thread wake-ups per step)")
+    ap.add_argument("--post-roll", type=float, default=2.0,
+                    help="seconds of the same steps after the timed region, reported as `sustained` (keeps the GPU busy "
+                         "long enough for an outside monitor to see the run; 0 disables)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            spawn_ranks(args.gpus, sys.argv[1:])      # does not return
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus and not os.environ.get("DH_BENCH_FORCE_DIST"):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={os.environ['WORLD_SIZE']}")
 
     if os.environ.get("DH_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack if the run stalls
         import faulthandler
@@ -167,6 +220,11 @@ def main():
     # (RCCL refuses two ranks on the same GPU); never set by the real multi-GPU launch
     if os.environ.get("DH_BENCH_SHARE_DEVICE"):
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} of {world} needs device {local_rank}, this machine shows "
+                         f"{torch.cuda.device_count()} (--gpus {world} needs {world} devices)")
+    # the CPU baseline runs first (rank 0 of a single-GPU run), so that the GPU work is the last thing the process does
+    base = cpu_baseline() if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
     backend = os.environ.get("DH_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -239,7 +297,15 @@ def main():
     early = overlap and not args.autograd and args.early_positives
     pos_stream = torch.cuda.Stream(priority=int(os.environ.get("DH_BENCH_POS_PRIORITY", "0"))) if early else None
     set_stream = torch.cuda.set_stream
-    split = {"prev_stats": None}
+    split = {"prev_stats": None, "reduced": None, "local_of_reduced": None}
+
+    def reduce_stats(mine):
+        """all_reduce(SUM) of one step's [lbox, lobj, lcls, n_pos] on the current (side) stream."""
+        if overlap:
+            mine.record_stream(torch.cuda.current_stream())      # made on the main stream, read on this one
+        mine = mine.clone() if backend == "nccl" else mine.cpu()   # (host tensor only in the gloo rehearsal)
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)               # over RCCL
+        return mine
 
     def launch(record, detail=False):
         """Enqueue one step's GPU work and the async copy of the NMS bookkeeping; no host synchronisation.
@@ -292,13 +358,10 @@ def main():
             # decode, which follows that loss on the main stream, so no event of its own is needed on the critical
             # stream (each one costs ~5 us there); one collective per step all the same.
             mine = split["prev_stats"] if overlap else stats
-            split["prev_stats"] = stats
+            split["prev_stats"] = stats if overlap else None
             if mine is not None:
-                if overlap:
-                    mine.record_stream(torch.cuda.current_stream())      # made on the main stream, read on this one
-                mine = mine.clone() if backend == "nccl" else mine.cpu()   # (host tensor only in the gloo rehearsal)
-                dist.all_reduce(mine, op=dist.ReduceOp.SUM)               # [lbox, lobj, lcls, n_pos] over RCCL
-                stats = mine
+                split["local_of_reduced"] = mine
+                stats = split["reduced"] = reduce_stats(mine)
         if overlap:
             set_stream(main_stream)
         h3 = time.perf_counter()
@@ -332,6 +395,15 @@ def main():
                 dets = finish(prev)      # prev's tensors are released here, so the allocator reuses its blocks
             prev = job
             all_marks.append((job["marks"], i % SAMPLE_EVERY == 0))
+        if dist_on and overlap and split["prev_stats"] is not None:
+            # the collective of step i rides with step i+1 (see launch); the last step's goes out here, inside the timed
+            # region: n steps, n collectives, every step's statistics reduced exactly once
+            set_stream(nms_stream)
+            nms_stream.wait_stream(main_stream)
+            split["reduced"] = reduce_stats(split["prev_stats"])
+            split["local_of_reduced"] = split["prev_stats"]
+            split["prev_stats"] = None
+            set_stream(main_stream)
         if prev is not None:
             dets = finish(prev)
         return all_marks, dets
@@ -361,10 +433,46 @@ def main():
         for s, (a, b) in zip(stages, ((0, 1), (6, 2), (3, 4), (4, 5))):
             if detail:
                 ev[s].append(marks[a].elapsed_time(marks[b]))
+    per_rank_ms = [elapsed / args.steps * 1e3]
+    collective_check = None
     if dist_on:
-        tmax = torch.tensor([elapsed], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        cdev = device if backend == "nccl" else "cpu"
+        mine_t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        every = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(every, mine_t)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)          # the job is as slow as its slowest rank
+        # the last step's reduced vector against the sum of what each rank put in (gathered outside the timed region)
+        local = split["local_of_reduced"].detach().to(cdev, torch.float32)
+        parts = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+        want = torch.stack(parts).sum(0)
+        got = split["reduced"].to(cdev)
+        collective_check = {"reduced": [round(float(v), 6) for v in got.tolist()],
+                            "sum_over_ranks": [round(float(v), 6) for v in want.tolist()],
+                            "ok": bool(torch.allclose(got, want, rtol=1e-6, atol=0.0))}
+
+    # Untimed post-roll: the same steps for a couple of seconds.  The timed region above is a few dozen milliseconds,
+    # which a once-per-second utilisation monitor never sees; this one it does, and its rate is reported beside `value`.
+    sustained = None
+    if args.post_roll > 0:
+        chunk = max(args.steps, 50)
+        sync_all()
+        p0, done_steps = time.perf_counter(), 0
+        while True:
+            run(chunk, False)
+            done_steps += chunk
+            go_on = torch.tensor([1.0 if time.perf_counter() - p0 < args.post_roll else 0.0],
+                                 device=device if (dist_on and backend == "nccl") else "cpu")
+            if dist_on:
+                dist.all_reduce(go_on, op=dist.ReduceOp.MIN)      # every rank leaves the loop after the same chunk
+            if float(go_on.item()) == 0.0:
+                break
+        sync_all()
+        psec = time.perf_counter() - p0
+        sustained = {"steps": done_steps, "seconds": round(psec, 3), "ms_per_step": round(psec / done_steps * 1e3, 4),
+                     "images_per_s": round(bs * world * done_steps / psec, 1),
+                     "note": "untimed post-roll of the same steps, this rank's clock, includes one host sync per chunk"}
 
     ms_per_step = elapsed / args.steps * 1e3
     value = bs * world * args.steps / elapsed
@@ -374,14 +482,18 @@ def main():
     decode_bytes = 680.0 * A * bs
     decode_s = stage_ms["decode"] * 1e-3
     achieved = decode_bytes / decode_s / 1e9
-    pmc = load_pmc_traffic()
+    pmc, pmc_path = load_pmc_traffic()
+    prof_ms = pmc.get("per_launch", {}).get("k_yolo_decode", {}).get("avg_us", 0.0) / 1e3
     roofline = {"kernel": "k_yolo_decode", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc.get("k_yolo_decode_bytes_per_launch"),
+                "measured": "HIP events around the launch on its stream, this run (every 4th timed step)",
+                # NOT measured in this run: the PMC counters need rocprofv3; the figure is read from the committed summary
+                "traffic": pmc.get("k_yolo_decode_bytes_per_launch"), "traffic_source": pmc_path,
                 "algorithmic_bytes_per_launch": decode_bytes, "avg_launch_ms": round(stage_ms["decode"], 4),
-                # the same kernel's average in the committed rocprofv3 --kernel-trace --stats run of this command
-                # (the event bracket above adds the two marker packets and the dispatch latency to it)
-                "rocprof_avg_launch_ms": round(pmc.get("per_launch", {}).get("k_yolo_decode", {}).get("avg_us", 0.0) / 1e3, 4) or None}
+                # the same kernel's average in the committed rocprofv3 --kernel-trace --stats run of this command (the
+                # event bracket above adds the two marker packets and the dispatch latency to it), and the fraction it gives
+                "rocprof_avg_launch_ms": round(prof_ms, 4) or None, "rocprof_source": pmc_path if prof_ms else None,
+                "frac_rocprof": round(decode_bytes / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if prof_ms else None}
 
     # the measured ceiling beside the nominal one: a plain device-to-device copy moving the same bytes as one decode
     # launch (the same read + write mix), timed alone after the timed region
@@ -415,7 +527,11 @@ def main():
             "host_step_interval_ms": {k: round(float(v) * 1e3, 4) for k, v in zip(
                 ("p10", "p50", "p90", "max", "argmax"), list(np.percentile(np.diff(step_wall), (10, 50, 90, 100))) +
                 [int(np.argmax(np.diff(step_wall))) * 1e-3])} if len(step_wall) > 2 else None,
-            "collective": "one all_reduce(SUM) of [lbox, lobj, lcls, n_pos] per step over RCCL, on the side stream" if world > 1 else None,
+            "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
+            "collective": ("one all_reduce(SUM) of [lbox, lobj, lcls, n_pos] per step over RCCL on the side stream; step i's "
+                           "vector travels while step i+1 is enqueued, the last step's inside the timed region") if dist_on else None,
+            "collective_check": collective_check,
+            "sustained": sustained,
             "loss_call": "crit(p,t) + torch.autograd.grad" if args.autograd else (
                 "crit.positives(p,t) on a side stream beside the decode, then crit.forward_backward(p,t,positives=...)" if early
                 else "crit.forward_backward(p,t)"),
@@ -423,8 +539,8 @@ def main():
                         3: "decode | nms chain | assign+loss on three streams (stage_ms overlap)"}[n_streams],
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if base is not None:
+            line["cpu_baseline"] = base
         print(json.dumps(line))
     if dist_on:
         dist.destroy_process_group()

@@ -29,3 +29,24 @@ def test_lazy_maps_are_recognised_by_layout_only_on_the_device():
     assert conv_layout_of([view]) is None                       # a CPU tensor never takes the kernel path
     assert conv_layout_of([view.contiguous()]) is None
     assert conv_layout_of([]) is None
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus N` starts N ranks itself; on a machine with fewer devices it says so and stops (it must
+    never report n_gpus 1 for a run that asked for more)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    n = max(torch.cuda.device_count() + 1, 2)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert f"needs {n} devices" in r.stderr
+    assert r.stdout.strip() == ""
+    # a launcher whose WORLD_SIZE disagrees with --gpus is an error, too
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
