@@ -8,7 +8,7 @@
  * Conventions
  *   - plain pointers and sizes only; all tensors are contiguous fp32 unless a stride is passed;
  *   - the caller owns every buffer, including `workspace` (size from the matching *_workspace());
- *     the library never allocates, frees or synchronises;
+ *     the library never allocates, frees or synchronises (dh_nms_plain_noalloc brings its own fixed workspace);
  *   - `stream` is a hipStream_t; kernels are enqueued on it and the call returns immediately;
  *   - return value: 0 = ok, DH_ERR_* < 0 otherwise (no kernel is launched on an argument error);
  *   - vector paths need 16-byte aligned pointers (DH_ERR_ALIGN otherwise).
@@ -177,6 +177,16 @@ int dh_nms_merge(float* out, int* out_span, int bs, int nc, int cap, int max_nms
 size_t dh_nms_plain_workspace(int64_t n);
 int dh_nms_plain(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
                  int* keep_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* dh_nms_plain for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): no counterpart in the reference.  Same inputs, outputs and results as dh_nms_plain
+ * with no workspace argument: the kernels work on a fixed 2.25 MiB device array that is part of the library (every GPU
+ * the library runs on holds its own copy until the process ends).  n <= 32768, larger inputs return DH_ERR_TOO_LARGE (-5).
+ * The call allocates and frees nothing.  All calls on one GPU share that array: calls that overlap on one GPU (two
+ * streams, two threads) race; serialise them.  The first call on a device looks the array's address up
+ * (hipGetSymbolAddress), so make one call outside graph capture before capturing. */
+int dh_nms_plain_noalloc(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
+                         int* keep_count, void* stream);
 
 /* xywh2xyxy (mode 0) / xyxy2xywh (mode 1) on the first four columns of n rows
  * (object_detection/yolov5/utils/general.py:543-560); strides in floats; in == out is allowed. */

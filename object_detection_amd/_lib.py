@@ -15,7 +15,8 @@ c_void_p, c_int, c_i64, c_double, c_float, c_size_t = (
     ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_float, ctypes.c_size_t)
 
 ERRORS = {-1: "invalid argument (shape / null pointer / unsupported size)", -2: "HIP kernel launch failed",
-          -3: "pointer not 16-byte aligned", -4: "workspace too small"}
+          -3: "pointer not 16-byte aligned", -4: "workspace too small",
+          -5: "input exceeds the fixed capacity of an entry point that allocates nothing"}
 
 # name -> (restype, argtypes); must list every symbol include/dethead.h declares
 SIGNATURES = {
@@ -59,6 +60,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_nms_plain_workspace": (c_size_t, [c_i64]),
     "dh_nms_plain": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_nms_plain_noalloc": (c_int, [c_void_p, c_void_p, c_i64, c_double, c_void_p, c_void_p, c_void_p]),
     "dh_box_convert": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_i64, c_int, c_void_p]),
     "dh_scale_clip_coords": (c_int, [c_void_p, c_i64, c_i64, c_int, c_double, c_double, c_double, c_double, c_double,
                                      c_void_p]),

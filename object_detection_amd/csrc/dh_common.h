@@ -8,6 +8,7 @@
 #define DH_ERR_LAUNCH (-2)   // hipGetLastError() after a launch was not hipSuccess
 #define DH_ERR_ALIGN (-3)    // pointer not aligned as the kernel requires
 #define DH_ERR_WORKSPACE (-4)  // workspace too small
+#define DH_ERR_TOO_LARGE (-5)  // problem exceeds the fixed capacity of an entry point that allocates nothing
 
 #define DH_WAVE 64
 

@@ -23,6 +23,8 @@
 //   6 collect     ballot/prefix-scan compaction of kept ranks in rank order, first max_det rows out
 // Cross-class pairs are skipped only when the image's coordinate range proves they cannot intersect
 // after the 7680-px class offset; otherwise that image is handled as one segment with per-box offsets.
+#include <mutex>
+
 #include "dh_common.h"
 #include "dh_decode.h"
 #include "../../include/dethead.h"
@@ -1904,14 +1906,11 @@ extern "C" size_t dh_nms_plain_workspace(int64_t n)
     return make_layout(1, (int)n, (int)n, 1, false).total;
 }
 
-extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
-                            int* keep_count, void* workspace, size_t workspace_bytes, void* stream)
+namespace {
+
+int nms_plain_run(const float* boxes, const float* scores, int ni, double iou_thres, int64_t* keep_index, int* keep_count,
+                  void* workspace, size_t workspace_bytes, hipStream_t st)
 {
-    if (n < 0 || n >= (1ll << 31) || !keep_count) return DH_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
-    if (!boxes || !scores || !keep_index || !workspace) return DH_ERR_ARG;
-    const int ni = (int)n;
     const nms_layout L = make_layout(1, ni, ni, 1, false);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
@@ -1935,4 +1934,55 @@ extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, 
                        (const int*)nullptr, ni, (float*)nullptr, (long long*)keep_index, keep_count, (int*)nullptr,
                        (int2*)nullptr, (int*)nullptr, (int*)nullptr);
     return dh_launch_status();
+}
+
+}  // namespace
+
+extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
+                            int* keep_count, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (n < 0 || n >= (1ll << 31) || !keep_count) return DH_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (!boxes || !scores || !keep_index || !workspace) return DH_ERR_ARG;
+    return nms_plain_run(boxes, scores, (int)n, iou_thres, keep_index, keep_count, workspace, workspace_bytes, st);
+}
+
+// ------------------------------------------------------------------------------------------ nms() without any allocation
+// The same launches as dh_nms_plain on a workspace that is part of the library's own image: a file-scope device array
+// (one copy per GPU, at its own address, held until the process ends).  In host code the array's name is only a handle
+// for the symbol; its device address comes from hipGetSymbolAddress, once per device, and everything below uses that.
+#define NOALLOC_MAX_BOXES 32768
+#define NOALLOC_SCRATCH_BYTES (2304u * 1024u)
+#define NOALLOC_MAX_DEVICES 64
+
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+namespace {
+std::mutex g_scratch_lock;
+void* g_scratch_ptr[NOALLOC_MAX_DEVICES];      // device address of `scratch` on each GPU (null: not looked up yet)
+}  // namespace
+
+extern "C" int dh_nms_plain_noalloc(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
+                                    int* keep_count, void* stream)
+{
+    if (n < 0 || !keep_count) return DH_ERR_ARG;
+    if (n > NOALLOC_MAX_BOXES) return DH_ERR_TOO_LARGE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (!boxes || !scores || !keep_index) return DH_ERR_ARG;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) return DH_ERR_ARG;
+    void* ws = nullptr;
+    {
+        std::lock_guard<std::mutex> hold(g_scratch_lock);
+        if (!g_scratch_ptr[dev]) {          // first call on this device (which is current): look the array's address up
+            void* found = nullptr;
+            if (hipGetSymbolAddress(&found, HIP_SYMBOL(scratch)) != hipSuccess || !found) return DH_ERR_LAUNCH;
+            g_scratch_ptr[dev] = found;
+        }
+        ws = g_scratch_ptr[dev];
+    }
+    if (make_layout(1, (int)n, (int)n, 1, false).total > NOALLOC_SCRATCH_BYTES) return DH_ERR_TOO_LARGE;
+    return nms_plain_run(boxes, scores, (int)n, iou_thres, keep_index, keep_count, ws, NOALLOC_SCRATCH_BYTES, st);
 }
