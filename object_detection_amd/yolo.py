@@ -57,17 +57,20 @@ def objectness_logits(maps):
 
 def _anchor_pixels(anchors, stride):
     """Host copies of anchor_grid (= anchors[i] * stride[i], yolo.py:79, formed in fp32 like the reference)
-    and of the strides; cached per anchors tensor version so the steady state does no device-to-host copy."""
-    key = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), id(stride))
+    and of the strides; cached per anchors tensor (the very object, at its version) and stride values, so the
+    steady state does no device-to-host copy."""
+    svals = tuple(float(v) for v in (stride.tolist() if isinstance(stride, torch.Tensor) else stride))
+    key = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), svals)
     hit = _ANCHOR_CACHE.get(key)
-    if hit is None:
-        anc = anchors.detach().float().cpu()
-        strd = torch.as_tensor(stride).detach().float().cpu()
-        hit = (L.float_array((anc * strd.view(-1, 1, 1)).reshape(-1).tolist()), L.float_array(strd.tolist()))
-        if len(_ANCHOR_CACHE) > 64:
-            _ANCHOR_CACHE.clear()
-        _ANCHOR_CACHE[key] = hit
-    return hit
+    if hit is not None and hit[0]() is anchors:      # same address and version but another tensor: reused storage
+        return hit[1]
+    anc = anchors.detach().float().cpu()
+    strd = torch.tensor(svals, dtype=torch.float32)
+    made = (L.float_array((anc * strd.view(-1, 1, 1)).reshape(-1).tolist()), L.float_array(strd.tolist()))
+    if len(_ANCHOR_CACHE) > 64:
+        _ANCHOR_CACHE.clear()
+    _ANCHOR_CACHE[key] = (weakref.ref(anchors), made)
+    return made
 
 
 def detect_decode(levels, anchors, stride):
@@ -268,9 +271,20 @@ class Detect(nn.Module):
             return conv_nms(convs, self.na, self.anchors, self.stride, conf_thres, iou_thres, classes, agnostic, multi_label,
                             max_det)
 
+    def _make_grid(self, nx=20, ny=20, i=0):
+        """yolo.py:72-81: cell indices (x, y) and anchors in pixels, both (1, na, ny, nx, 2).  The decode kernel derives
+        them from the row index; the attributes are kept for callers that read them (export, plotting)."""
+        d = self.anchors[i].device
+        yv, xv = torch.meshgrid([torch.arange(ny, device=d), torch.arange(nx, device=d)], indexing='ij')
+        grid = torch.stack((xv, yv), 2).expand((1, self.na, ny, nx, 2)).float()
+        anchor_grid = (self.anchors[i].clone() * self.stride[i]).view((1, self.na, 1, 1, 2)).expand((1, self.na, ny, nx, 2)).float()
+        return grid, anchor_grid
+
     def forward(self, x):
         for i in range(self.nl):
             x[i] = self.m[i](x[i])
+            if not self.training and (self.onnx_dynamic or self.grid[i].shape[2:4] != x[i].shape[2:4]):   # yolo.py:57-58
+                self.grid[i], self.anchor_grid[i] = self._make_grid(int(x[i].shape[3]), int(x[i].shape[2]), i)
         if self.training and self.lazy_maps:
             for i in range(self.nl):
                 bs, _, ny, nx = x[i].shape

@@ -1,0 +1,116 @@
+"""The benchmark configurations at their configured sizes against the CPU oracle (bit-exact NMS rows):
+  config 3  dense pre-NMS stress, 32 images x 100 000 boxes x 80 classes, conf 0.25: more than 30 000 candidates per
+            image, so the top-30 000 cut of general.py:716-717 decides what reaches NMS;
+  config 5  one GPU's share of the 1280 px sweep, 16 images x 100 800 anchors, conf 0.001 / IoU 0.6 / multi-label
+            (val.py:203).
+The oracle handles one image per call, so the images are spread over a few host threads (its C and torch parts both
+release the interpreter lock)."""
+import math
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms as onms
+from oracle import yolo as oy
+from tests._checks import decoded_close, level_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_nms_per_image(pred_cpu, workers=8, **kw):
+    with ThreadPoolExecutor(workers) as pool:
+        return [r[0] for r in pool.map(lambda b: onms.non_max_suppression(pred_cpu[b:b + 1].clone(), **kw), range(pred_cpu.shape[0]))]
+
+
+def same_lists(got, want):
+    assert [int(g.shape[0]) for g in got] == [int(w.shape[0]) for w in want]
+    for g, w in zip(got, want):
+        assert torch.equal(g.cpu(), w)
+
+
+def dense_pred(bs, A, nc, seed=3):
+    """xy ~ U(0, 640), wh ~ LogUniform(4, 256), obj ~ U(0.3, 1), class scores softmax(N(0, 3)); made on the device."""
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(seed)
+    pred = torch.empty((bs, A, 5 + nc), device=dev)
+    pred[..., 0:2] = torch.rand((bs, A, 2), generator=g, device=dev) * 640
+    pred[..., 2:4] = torch.exp(torch.rand((bs, A, 2), generator=g, device=dev) * (math.log(256) - math.log(4)) + math.log(4))
+    pred[..., 4] = torch.rand((bs, A), generator=g, device=dev) * 0.7 + 0.3
+    for b in range(bs):      # image by image: the softmax temporary of the whole batch would be another GB
+        pred[b, :, 5:] = torch.softmax(torch.randn((A, nc), generator=g, device=dev) * 3, -1)
+    return pred
+
+
+def dedupe_best_scores(pred):
+    """Single-label scores (obj * best class, general.py:691,701) made pairwise different inside every image by
+    lowering the objectness of the later row of an equal pair by one ulp, until none is left."""
+    for _ in range(50):
+        conf = (pred[..., 5:] * pred[..., 4:5]).amax(-1)                       # (bs, A), the products the kernels form
+        order = torch.argsort(conf, dim=1, stable=True)
+        s = torch.gather(conf, 1, order)
+        dup = torch.zeros_like(conf, dtype=torch.bool)
+        dup.scatter_(1, order[:, 1:], s[:, 1:] == s[:, :-1])
+        if not bool(dup.any()):
+            return pred
+        pred[..., 4] = torch.where(dup, torch.nextafter(pred[..., 4], torch.zeros_like(pred[..., 4])), pred[..., 4])
+    raise RuntimeError("could not de-duplicate the scores")
+
+
+def test_config3_dense_stress_32x100000_vs_oracle():
+    from object_detection_amd.general import non_max_suppression
+    bs, A, nc = 32, 100_000, 80
+    pred = dedupe_best_scores(dense_pred(bs, A, nc))
+    conf = (pred[..., 5:] * pred[..., 4:5]).amax(-1)
+    survivors = ((pred[..., 4] > 0.25) & (conf > 0.25)).sum(1)
+    assert int(survivors.min()) > 30_000, survivors.tolist()                 # every image goes through the top-30 000 cut
+    kw = dict(conf_thres=0.25, iou_thres=0.45, max_det=300)
+    got = non_max_suppression(pred, **kw)
+    got_again = non_max_suppression(pred, **kw)                                # second call: the attempt chosen from the first
+    host = pred.cpu()
+    want = oracle_nms_per_image(host, **kw)
+    same_lists(got, want)
+    same_lists(got_again, want)
+    assert all(int(w.shape[0]) == 300 for w in want)
+    # a larger max_det reaches far below the selected prefix (general path, full sort) -- first 8 images
+    kw_deep = dict(conf_thres=0.25, iou_thres=0.45, max_det=5000)
+    same_lists(non_max_suppression(pred[:8], **kw_deep), oracle_nms_per_image(host[:8], **kw_deep))
+    del got, got_again, want
+    # 1 % of the rows repeat another row's objectness and class scores: equal scores, resolved by candidate order
+    # (the stable refinement of the reference's unstable sorts) -- first 8 images
+    sub = pred[:8].clone()
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    dst = torch.randperm(A, generator=gen, device="cuda")[:A // 100]
+    src = torch.randint(0, A, (A // 100,), generator=gen, device="cuda")
+    sub[:, dst, 4:] = sub[:, src, 4:]
+    for kw_t in (kw, kw_deep):
+        same_lists(non_max_suppression(sub, **kw_t), oracle_nms_per_image(sub.cpu(), **kw_t))
+
+
+def test_config5_sweep_share_16x100800_vs_oracle():
+    """decode (per-group tolerance) and NMS at validation thresholds (bit-exact on the oracle's decoded tensor) for one
+    GPU's share of the 1280 px sweep; conv_nms / detect_nms on the same head equal the two-step path bit for bit."""
+    from object_detection_amd.general import conv_nms, non_max_suppression
+    from object_detection_amd.yolo import head_maps_decode
+    from tests.test_gpu_conv_nms import _head
+    convs = _head(5, 16, 1280, 80, frac=0.001)
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    dec, maps = head_maps_decode(convs, 3, anchors, stride)
+    assert dec.shape == (16, 100800, 85)
+    want_maps = oy.head_maps([c.cpu() for c in convs], 3)
+    want_dec = oy.detect_decode(want_maps, anchors.cpu(), oy.YOLOV5S_STRIDES)
+    for m, w in zip(maps, want_maps):
+        assert torch.equal(m.cpu(), w)
+    decoded_close(dec, want_dec, level_rows(maps), oy.YOLOV5S_STRIDES)
+    kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    want = oracle_nms_per_image(want_dec, **kw)
+    same_lists(non_max_suppression(want_dec.cuda(), **kw), want)
+    assert sum(int(w.shape[0]) for w in want) > 16 * 100
+    # the fused entries on the device's own decode
+    two_step = non_max_suppression(dec, **kw)
+    for g, w in zip(conv_nms(convs, 3, anchors, stride, **kw), two_step):
+        assert torch.equal(g, w)
+    # and the device's rows against the oracle's: same counts unless a score sits within rounding of a threshold
+    close_counts = sum(int(a.shape[0] == b.shape[0]) for a, b in zip(two_step, want))
+    assert close_counts >= 14

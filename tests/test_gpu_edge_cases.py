@@ -8,6 +8,7 @@ from oracle import nms as onms
 from oracle import yolo as oy
 from tests._synth import synth_head, synth_pred, synth_targets
 from tests.test_gpu_nms import same_lists
+from tests._checks import decoded_close, level_rows
 from tests.test_gpu_yolo_loss import FakeModel, close
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +55,7 @@ def test_decode_scalar_path_and_single_class():
     want = oy.detect_decode([T(x) for x in levels], anchors, strides)
     dev = [T(x).cuda() for x in levels]
     got = detect_decode(dev, anchors.cuda(), torch.tensor(strides))
-    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5 * 16)
+    decoded_close(got, want, level_rows(levels), strides)
     for kw in (dict(conf_thres=0.05, iou_thres=0.3), dict(conf_thres=0.05, iou_thres=0.3, multi_label=True)):
         two = non_max_suppression(got, **kw)
         same_lists(two, onms.non_max_suppression(got.cpu().clone(), **kw))
@@ -165,7 +166,7 @@ def test_loss_and_decode_with_more_levels(strides):
         close(a, b)
     z = detect_decode([x.detach() for x in d], anchors.cuda(), torch.tensor(strides))
     want = oy.detect_decode([T(x) for x in levels], anchors, list(strides))
-    np.testing.assert_allclose(z.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5 * strides[-1])
+    decoded_close(z, want, level_rows(levels), strides)
 
 
 def test_1280px_head_decode_nms_vs_oracle():
@@ -186,7 +187,7 @@ def test_1280px_head_decode_nms_vs_oracle():
     z = detect_decode(dev, anchors.cuda(), strides)
     assert z.shape == (1, 100800, 85)
     want = oy.detect_decode([T(x) for x in levels], anchors, oy.YOLOV5S_STRIDES)
-    np.testing.assert_allclose(z.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5 * 32)
+    decoded_close(z, want, level_rows(levels), oy.YOLOV5S_STRIDES)
     kw = dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
     ref = onms.non_max_suppression(z.cpu().clone(), **kw)
     same_lists(non_max_suppression(z, **kw), ref)

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from oracle import yolo as oy
+from tests._checks import decoded_close, level_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +60,7 @@ def test_head_maps_decode_equals_two_steps(bs, na, no, shapes):
     assert torch.equal(yolo.objectness_logits(maps), yolo.objectness_logits(ref_maps))
     assert torch.equal(yolo.objectness_plane(dec), dec[:, :, 4])
     want = oy.detect_decode(oy.head_maps([c.cpu() for c in convs], na), anchors.cpu(), stride.tolist())
-    torch.testing.assert_close(dec.cpu(), want, rtol=1e-5, atol=1e-5)
+    decoded_close(dec, want, level_rows(maps), stride.tolist())
 
 
 @pytest.mark.parametrize("bs,na,no,shapes", CASES)
@@ -154,7 +155,7 @@ def test_detect_module_eval_and_train_match_the_reference_forward():
     for a, b in zip(x, ref_maps):
         assert torch.equal(a.cpu(), b)
     want = oy.detect_decode(ref_maps, det.anchors.cpu(), oy.YOLOV5S_STRIDES)
-    torch.testing.assert_close(z.cpu(), want, rtol=1e-5, atol=1e-5)
+    decoded_close(z, want, level_rows(ref_maps), oy.YOLOV5S_STRIDES)
     det.train()
     x = det([f.clone().requires_grad_() for f in feats])
     for a, b in zip(x, ref_maps):
@@ -182,3 +183,37 @@ def test_head_maps_full_size_round_trip():
     torch.autograd.backward(out, [o.detach() for o in out])
     for c, l in zip(convs, leaf):
         assert torch.equal(l.grad, c)
+
+
+@pytest.mark.parametrize("tag", ["s3_nc80", "s3_nc80_cat", "s3_nc7_rect", "s3_nc1", "s4_nc7", "s5_nc3_na2"])
+def test_detect_against_the_reference_class(golden, tag):
+    """tests/golden/detect.npz holds Detect.forward of the reference's own class (models/yolo.py:49-81) on the CPU:
+    the outputs of its convolutions, its maps and its decoded tensor.  Maps: bit-exact (no arithmetic).  Decoded tensor:
+    xy within 1e-5 * stride px, wh / objectness / classes 1e-5 relative (the device's exp against the CPU's)."""
+    from object_detection_amd import yolo
+    g = golden("detect")
+    nc, na, nl, _, bs = (int(v) for v in g[f"{tag}_meta"])
+    convs = [torch.from_numpy(g[f"{tag}_conv{l}"]).cuda() for l in range(nl)]
+    anchors, strides = torch.from_numpy(g[f"{tag}_anchors"]).cuda(), torch.from_numpy(g[f"{tag}_strides"])
+    want_maps = oy.head_maps([c.cpu() for c in convs], na)          # == the reference's maps (test_oracle_golden)
+    want_z = torch.from_numpy(g[f"{tag}_z"])
+    z, maps = yolo.head_maps_decode(convs, na, anchors, strides)
+    for m, w in zip(maps, want_maps):
+        assert torch.equal(m.cpu(), w)
+    decoded_close(z, want_z, level_rows(maps), strides.tolist())
+    z2 = yolo.detect_decode(yolo.head_maps(convs, na), anchors, strides)
+    assert torch.equal(z2, z)
+    # the module: same weights, the reference's attributes after an eval pass
+    det = yolo.Detect(nc=nc, anchors=[[1.0] * (2 * na)] * nl, ch=[int(g[f"{tag}_w{l}"].shape[1]) for l in range(nl)]).cuda().eval()
+    det.stride = strides
+    with torch.no_grad():
+        det.anchors.copy_(anchors)
+        for l in range(nl):
+            det.m[l].weight.copy_(torch.from_numpy(g[f"{tag}_w{l}"]))
+            det.m[l].bias.copy_(torch.from_numpy(g[f"{tag}_b{l}"]))
+        feats = [torch.zeros(bs, int(g[f"{tag}_w{l}"].shape[1]), c.shape[2], c.shape[3], device="cuda") for l, c in enumerate(convs)]
+        zm, xm = det(feats)
+    assert zm.shape == want_z.shape and [tuple(a.shape) for a in xm] == [tuple(w.shape) for w in want_maps]
+    for l in range(nl):
+        assert torch.equal(det.grid[l].cpu(), torch.from_numpy(g[f"{tag}_grid{l}"]))
+        assert torch.equal(det.anchor_grid[l].cpu(), torch.from_numpy(g[f"{tag}_anchor_grid{l}"]))

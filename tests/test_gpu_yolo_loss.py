@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import yolo as oy
+from tests._checks import decoded_close, level_rows
 from tests._synth import synth_head, synth_targets
 from tests.test_oracle_golden import HYP_KEYS
 
@@ -162,7 +163,7 @@ def test_full_size_bs64_640_pipeline_vs_oracle():
     del gg, wg, fg
     wz = oy.detect_decode([T(x) for x in levels], anchors, oy.YOLOV5S_STRIDES)
     gz = detect_decode([x.detach() for x in d], anchors.cuda(), torch.tensor(oy.YOLOV5S_STRIDES))
-    close(gz, wz)
+    decoded_close(gz, wz, level_rows(levels), oy.YOLOV5S_STRIDES)
     # NMS is fed the oracle's decoded tensor so that the comparison is exact (stage-wise parity)
     for kw in (dict(conf_thres=0.25, iou_thres=0.45, max_det=300), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)):
         want = onms.non_max_suppression(wz.clone(), **kw)

@@ -418,3 +418,23 @@ def test_regression_loss_oracle_vs_reference(golden, tag):
     grad, = torch.autograd.grad(loss * 2.0, x)
     np.testing.assert_allclose(loss.detach().numpy(), g[f"{tag}_loss"], rtol=1e-6)
     np.testing.assert_allclose(grad.numpy(), g[f"{tag}_grad"], rtol=1e-6, atol=1e-9)
+
+
+DETECT_TAGS = ["s3_nc80", "s3_nc80_cat", "s3_nc7_rect", "s3_nc1", "s4_nc7", "s5_nc3_na2"]
+
+
+@pytest.mark.parametrize("tag", DETECT_TAGS)
+def test_detect_head_maps_and_decode(golden, tag):
+    """Detect.forward of the reference's own class (models/yolo.py:49-81, compiled from its file by
+    tools/make_golden.py): 3 / 4 / 5 levels, nc 1 / 7 / 80, rectangular grids, both the in-place and the
+    concatenating decode.  The oracle repeats the same torch operations in the same order: bit-exact."""
+    g = golden("detect")
+    nc, na, nl, _, bs = (int(v) for v in g[f"{tag}_meta"])
+    convs = [T(g[f"{tag}_conv{l}"]) for l in range(nl)]
+    maps = oy.head_maps(convs, na)
+    z = oy.detect_decode(maps, T(g[f"{tag}_anchors"]), [float(s) for s in g[f"{tag}_strides"]])
+    assert z.shape == g[f"{tag}_z"].shape and z.shape[0] == bs and z.shape[2] == nc + 5
+    np.testing.assert_array_equal(z.numpy(), g[f"{tag}_z"])
+    for l, m in enumerate(maps):      # anchor_grid = anchors * stride, grid = (x, y) cell indices (yolo.py:72-81)
+        assert tuple(g[f"{tag}_grid{l}"].shape) == (1, na, m.shape[2], m.shape[3], 2)
+        np.testing.assert_array_equal(g[f"{tag}_anchor_grid{l}"][0, :, 0, 0], g[f"{tag}_anchors"][l] * g[f"{tag}_strides"][l])

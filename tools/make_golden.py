@@ -621,6 +621,84 @@ def gen_tta():
     save("tta", **out)
 
 
+def reference_detect_class(y_general):
+    """The `Detect` class of models/yolo.py:33-81, compiled from the reference's own file: the module cannot be imported
+    (models/common.py and utils/plots.py reach the network at import time), but the class needs nothing beyond torch,
+    torch.nn and utils.general.check_version, so its definition alone is taken from the syntax tree."""
+    import ast
+    path = os.path.join(REF, "yolov5", "models", "yolo.py")
+    tree = ast.parse(open(path).read(), path)
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Detect"]
+    ns = {"torch": torch, "nn": torch.nn, "check_version": y_general.check_version}
+    exec(compile(ast.Module(body=cls, type_ignores=[]), path, "exec"), ns)
+    return ns["Detect"]
+
+
+DETECT_CASES = {      # tag: (nc, anchors in pixels per level, strides, input channels, (H, W) of the image, batch, inplace)
+    "s3_nc80": (80, None, (8, 16, 32), (4, 8, 16), (64, 96), 2, True),
+    "s3_nc80_cat": (80, None, (8, 16, 32), (4, 8, 16), (64, 96), 2, False),
+    "s3_nc7_rect": (7, None, (8, 16, 32), (3, 5, 7), (160, 96), 3, True),
+    "s3_nc1": (1, None, (8, 16, 32), (2, 2, 2), (96, 96), 1, True),
+    "s4_nc7": (7, ((19, 27, 44, 40, 38, 94), (96, 68, 86, 152, 180, 137), (140, 301, 303, 264, 238, 542),
+                   (436, 615, 739, 380, 925, 792)), (8, 16, 32, 64), (3, 4, 5, 6), (128, 192), 2, True),
+    "s5_nc3_na2": (3, ((10, 13, 16, 30), (30, 61, 62, 45), (59, 119, 116, 90), (156, 198, 373, 326), (400, 500, 600, 640)),
+                   (4, 8, 16, 32, 64), (2, 3, 4, 5, 6), (128, 64), 2, False),
+}
+
+
+def detect_case_inputs(tag):
+    """Seeded feature maps of a case (rebuilt by the tests: the fixture stores the convolution outputs, not these)."""
+    nc, anchors_px, strides, ch, (H, W), bs, inplace = DETECT_CASES[tag]
+    rs = np.random.RandomState(sum(map(ord, tag)))
+    return [f32(rs.normal(0, 1, (bs, c, H // s, W // s))) for c, s in zip(ch, strides)]
+
+
+def gen_detect(y_general):
+    """Detect.forward (models/yolo.py:49-81), training and inference branch, from the reference's own class: the outputs
+    of its 1x1 convolutions (computed by calling the module's own nn.Conv2d layers; the convolution itself is not on the
+    path), the maps of yolo.py:54 and the decoded tensor of yolo.py:56-70."""
+    from oracle import yolo as oy
+    Detect = reference_detect_class(y_general)
+    out = {}
+    for tag, (nc, anchors_px, strides, ch, hw, bs, inplace) in DETECT_CASES.items():
+        anchors_px = anchors_px or oy.YOLOV5S_ANCHORS_PX
+        torch.manual_seed(sum(map(ord, tag)))
+        det = Detect(nc=nc, anchors=anchors_px, ch=ch, inplace=inplace)
+        det.stride = torch.tensor([float(s) for s in strides])
+        det.anchors /= det.stride.view(-1, 1, 1)                                   # yolo.py:113
+        with torch.no_grad():
+            for m, s in zip(det.m, strides):                                       # yolo.py:196-204: realistic sparsity
+                b = m.bias.view(det.na, -1)
+                b[:, 4] += np.log(8 / (640 / s) ** 2)
+                b[:, 5:] += np.log(0.6 / (nc - 0.999999))
+                m.weight.mul_(3.0)
+        feats = [T(x) for x in detect_case_inputs(tag)]
+        with torch.no_grad():
+            convs = [m(x) for m, x in zip(det.m, feats)]
+            det.train()
+            maps_train = det([x.clone() for x in feats])
+            det.eval()
+            z, maps_eval = det([x.clone() for x in feats])
+        assert all(torch.equal(a, b) for a, b in zip(maps_train, maps_eval))
+        # the oracle's restatement against the reference, bit for bit (same torch operations in the same order)
+        mine_maps = oy.head_maps(convs, det.na)
+        assert all(torch.equal(a, b) for a, b in zip(mine_maps, maps_eval)), tag
+        mine_z = oy.detect_decode(mine_maps, det.anchors, [float(s) for s in strides])
+        assert torch.equal(mine_z, z), tag
+        out[f"{tag}_anchors"] = det.anchors.numpy().copy()
+        out[f"{tag}_meta"] = np.array([nc, det.na, det.nl, int(inplace), bs])
+        out[f"{tag}_strides"] = np.array(strides, dtype=np.float32)
+        out[f"{tag}_z"] = z.numpy()
+        for l in range(det.nl):
+            out[f"{tag}_conv{l}"] = convs[l].numpy()
+            out[f"{tag}_w{l}"] = det.m[l].weight.detach().numpy().copy()
+            out[f"{tag}_b{l}"] = det.m[l].bias.detach().numpy().copy()
+            out[f"{tag}_grid{l}"] = det.grid[l].numpy().copy()
+            out[f"{tag}_anchor_grid{l}"] = det.anchor_grid[l].numpy().copy()
+        print(f"  detect {tag}: z {tuple(z.shape)}, obj max {float(z[..., 4].max()):.4f}")
+    save("detect", **out)
+
+
 def ap_case(rs, n, nc, n_lab, niou=10, p_hit=0.6, absent=()):
     """Evaluation statistics as val.py collects them: tp (n, niou) bool (a hit at a higher IoU threshold implies the
     lower ones, at most one hit per label), conf (n,) float32 all different, pred_cls (n,) float32, target_cls (m,) float64."""
@@ -782,7 +860,7 @@ def main():
     only = set(sys.argv[1:])
     if only:                      # e.g. `make_golden.py ap`: regenerate the named fixtures only
         gens = {"ap": lambda: gen_ap(y_metrics), "evalmatch": lambda: gen_evalmatch(y_metrics), "tta": gen_tta,
-                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss), "nms_merge": lambda: gen_nms_merge(y_general)}
+                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss), "nms_merge": lambda: gen_nms_merge(y_general), "detect": lambda: gen_detect(y_general)}
         for k in only:
             gens[k]()
         return
@@ -796,6 +874,7 @@ def main():
     gen_centernet(a_loss, c_loss, c_data)
     gen_evalmatch(y_metrics)
     gen_tta()
+    gen_detect(y_general)
     gen_ap(y_metrics)
     gen_autoanchor()
     gen_focal(a_loss)
