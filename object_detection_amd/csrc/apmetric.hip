@@ -362,8 +362,8 @@ extern "C" int dh_ap_classes(const double* target_cls, int64_t m, int class_cap,
     if (m < 0 || class_cap < 1 || class_cap > (1 << 24) || !unique || !nt || !meta || !bins || (m > 0 && !target_cls))
         return DH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(bins, 0, sizeof(int) * class_cap, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (hipMemsetAsync(meta, 0, sizeof(int) * 2, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (dh_fill_async(bins, 0, sizeof(int) * class_cap, st) != DH_OK) return DH_ERR_LAUNCH;
+    if (dh_fill_async(meta, 0, sizeof(int) * 2, st) != DH_OK) return DH_ERR_LAUNCH;
     if (m > 0)
         hipLaunchKernelGGL(k_ap_hist, dim3((unsigned)((m + AP_THREADS * AP_HIST_PER_THREAD - 1) / (AP_THREADS * AP_HIST_PER_THREAD))),
                            dim3(AP_THREADS), 0, st, target_cls, (long)m, class_cap, bins, meta);

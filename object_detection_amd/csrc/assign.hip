@@ -235,8 +235,8 @@ int dh_launch_build_targets(const float* targets, int64_t nt, const float* ancho
     if (fill_bytes && (!fill || (fill_bytes & 15u) || !dh_aligned16(fill))) return DH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (nt == 0) {
-        if (fill_bytes && hipMemsetAsync(fill, 0xFF, fill_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
-        return hipMemsetAsync(counts, 0, sizeof(int) * nl, st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+        if (fill_bytes && dh_fill_async(fill, 0xFF, fill_bytes, st) != DH_OK) return DH_ERR_LAUNCH;
+        return dh_fill_async(counts, 0, sizeof(int) * nl, st);
     }
     if (!targets || !idx || !tbox || !anch || !tcls || !workspace || cap < 5ll * na * nt) return DH_ERR_ARG;
     if (workspace_bytes < dh_build_targets_workspace(nl, na, nt)) return DH_ERR_WORKSPACE;

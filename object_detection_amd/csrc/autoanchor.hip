@@ -57,7 +57,7 @@ extern "C" int dh_anchor_metric(const float* wh, int64_t N, const float* k, int 
 {
     if (N < 0 || n < 1 || n > AA_MAX_ANCHORS || !k || !sums || (N > 0 && !wh) || N * (int64_t)n >= (1ll << 40)) return DH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 3, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (dh_fill_async(sums, 0, sizeof(double) * 3, st) != DH_OK) return DH_ERR_LAUNCH;
     if (N == 0) return DH_OK;
     hipLaunchKernelGGL(k_anchor_metric, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, wh, (long)N, k, n, (float)thr, x, best,
                        sums);

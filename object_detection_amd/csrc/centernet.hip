@@ -482,11 +482,11 @@ extern "C" int dh_centernet_targets(const float* labels, const int* nlabels, int
     if (!t_cls || !t_size || !t_offset || !t_mask || !owner_ws || !nlabels) return DH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t cells = (size_t)W * H;
-    if (hipMemsetAsync(t_cls, 0, sizeof(float) * B * C * cells, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (hipMemsetAsync(t_size, 0, sizeof(float) * B * 2 * cells, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (hipMemsetAsync(t_offset, 0, sizeof(float) * B * 2 * cells, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (hipMemsetAsync(t_mask, 0, sizeof(float) * B * cells, st) != hipSuccess) return DH_ERR_LAUNCH;
-    if (hipMemsetAsync(owner_ws, 0xFF, sizeof(int) * B * cells, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (dh_fill_async(t_cls, 0, sizeof(float) * B * C * cells, st) != DH_OK) return DH_ERR_LAUNCH;
+    if (dh_fill_async(t_size, 0, sizeof(float) * B * 2 * cells, st) != DH_OK) return DH_ERR_LAUNCH;
+    if (dh_fill_async(t_offset, 0, sizeof(float) * B * 2 * cells, st) != DH_OK) return DH_ERR_LAUNCH;
+    if (dh_fill_async(t_mask, 0, sizeof(float) * B * cells, st) != DH_OK) return DH_ERR_LAUNCH;
+    if (dh_fill_async(owner_ws, 0xFF, sizeof(int) * B * cells, st) != DH_OK) return DH_ERR_LAUNCH;
     if (Lmax == 0) return DH_OK;
     if (!labels) return DH_ERR_ARG;
     const dim3 grid((Lmax + 255) / 256, B);

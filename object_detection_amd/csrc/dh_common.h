@@ -17,6 +17,39 @@ typedef float dh_f4 __attribute__((ext_vector_type(4)));   // native 16-byte vec
 static inline int dh_launch_status() { return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH; }
 static inline bool dh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Every fill of the library goes through this kernel, not through hipMemsetAsync.  A memset captured into a HIP graph is a
+// memset node, and on this runtime (ROCm 7.2) memset nodes are not reliable once several are replayed in turn: a captured
+// 12-byte fill with 0 that follows a 4-byte one wrote 0x0C bytes on every second replay (tools/graph_memset_probe.py).  The
+// NMS and loss bookkeeping start from an all-zero (or all-ones) state, so a wrong fill value there turns counters into wild
+// indices.  A kernel node replays like any other launch.
+template <typename V>
+__global__ void __launch_bounds__(256) dh_k_fill(V* __restrict__ p, V value, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+
+static inline int dh_fill_async(void* p, int byte_value, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return DH_OK;
+    if (!p) return DH_ERR_ARG;
+    const uint32_t b = (uint32_t)byte_value & 0xFFu, w = b * 0x01010101u;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    if (((a | bytes) & 15u) == 0 && bytes / 16 / 256 < (1ull << 31)) {
+        const size_t n = bytes / 16;
+        hipLaunchKernelGGL(dh_k_fill<uint4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint4*)p, make_uint4(w, w, w, w), n);
+    } else if (((a | bytes) & 3u) == 0 && bytes / 4 / 256 < (1ull << 31)) {
+        const size_t n = bytes / 4;
+        hipLaunchKernelGGL(dh_k_fill<uint32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, w, n);
+    } else if (bytes / 256 < (1ull << 31)) {
+        hipLaunchKernelGGL(dh_k_fill<unsigned char>, dim3((unsigned)((bytes + 255) / 256)), dim3(256), 0, st, (unsigned char*)p,
+                           (unsigned char)b, bytes);
+    } else {
+        return DH_ERR_ARG;
+    }
+    return dh_launch_status();
+}
+
 // Exact unsigned division by a runtime constant for numerators < 2^31:
 // q = (n * magic) >> 32 >> shift  (round-up method).  Built on the host, used on the device.
 struct dh_fastdiv {

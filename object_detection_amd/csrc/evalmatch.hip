@@ -175,7 +175,7 @@ int launch_match(bool confusion, const float* det, const float* labels, const in
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws + L.off_key, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;   // key 0 = label kept nothing
+    if (dh_fill_async(ws + L.off_key, 0, L.zero_bytes, st) != DH_OK) return DH_ERR_LAUNCH;   // key 0 = label kept nothing
     if (confusion)
         hipLaunchKernelGGL(k_eval_match<true>, dim3(n_img), dim3(EM_THREADS), 0, st, det, labels, det_first, label_first,
                            (int)n_det, (int)n_labels, thr, conf_thr, iouv, n_iou, nc, correct, matrix,

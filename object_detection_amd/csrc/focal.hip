@@ -300,7 +300,7 @@ extern "C" int dh_focal_loss_fwd(const float* logits, const void* labels, int64_
     if (rc != DH_OK) return rc;
     if (!out) return DH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (a.cells == 0) return hipMemsetAsync(out, 0xFF, sizeof(float), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;   // mean of nothing: NaN
+    if (a.cells == 0) return dh_fill_async(out, 0xFF, sizeof(float), st);   // mean of nothing: NaN
     const fl_ws W = fl_layout(a.cells);
     if (!workspace || workspace_bytes < W.total) return DH_ERR_WORKSPACE;
     if (!dh_aligned16(workspace)) return DH_ERR_ALIGN;
@@ -330,7 +330,7 @@ extern "C" int dh_focal_loss_bwd(const float* logits, const void* labels, int64_
     const size_t n_el = (size_t)a.cells * C;
     if (n_el % 4 == 0 && dh_aligned16(grad_logits) && n_el / 4 / 256 < (1ull << 31)) {
         hipLaunchKernelGGL(k_focal_zero, dim3((unsigned)((n_el / 4 + 255) / 256)), dim3(256), 0, st, (dh_f4*)grad_logits, n_el / 4);
-    } else if (hipMemsetAsync(grad_logits, 0, sizeof(float) * n_el, st) != hipSuccess) {
+    } else if (dh_fill_async(grad_logits, 0, sizeof(float) * n_el, st) != DH_OK) {
         return DH_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(k_focal_cells<true>, dim3((unsigned)W.blocks), dim3(256), 0, st, a,

@@ -1060,7 +1060,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
         s = 0; e = m;
     } else {
         const int2 sg = seg_all[(size_t)b * gridDim.x + blockIdx.x];
-        s = sg.x; e = sg.y;
+        s = sg.x < 0 ? 0 : sg.x;
+        e = sg.y > m ? m : sg.y;          // a segment lies inside the image's m rows whatever the table holds
         if (s >= e) return;
     }
     const float* __restrict__ dimg = det + (size_t)b * m_cap * 6;
@@ -1156,7 +1157,7 @@ __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ 
                                                       float* __restrict__ out, long long* __restrict__ out_index,
                                                       int* __restrict__ out_count, int* __restrict__ cursor,
                                                       int2* __restrict__ out_span, int* __restrict__ cand_count,
-                                                      int* __restrict__ needs_full)
+                                                      int* __restrict__ needs_full, int out_rows)
 {
     const int b = blockIdx.x;
     if (cand_count && threadIdx.x == 0) cand_count[b] = counts[b];
@@ -1200,7 +1201,7 @@ __global__ void __launch_bounds__(1024) k_nms_collect(const float* __restrict__ 
 #pragma unroll
         for (int w = 0; w < 16; ++w) { const int c = wcount[w]; if (w < wave) before += c; all += c; }
         const int pos = done + before + __popcll(bm & lanemask_lt());
-        if (k && pos < total) {
+        if (k && pos < total && (long long)first + pos < out_rows) {      // never beyond the caller's buffer, whatever the cursor holds
             if (out) {
                 const float* __restrict__ d = det + ((size_t)b * m_cap + r) * 6;
                 float* __restrict__ o = out + ((size_t)first + pos) * 6;
@@ -1227,7 +1228,7 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
                                                     int cap_pad, const int* __restrict__ counts, int cap, int agnostic,
                                                     float max_wh, float thr, int max_det, float* __restrict__ out,
                                                     int* __restrict__ cursor, int2* __restrict__ out_span,
-                                                    int* __restrict__ cand_count, int* __restrict__ needs_full)
+                                                    int* __restrict__ cand_count, int* __restrict__ needs_full, int out_rows)
 {
     __shared__ u64 s_key[SMALL_MAX];
     __shared__ float4 s_box[SMALL_MAX];         // unshifted x1,y1,x2,y2 in score order
@@ -1349,7 +1350,7 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
 #pragma unroll
     for (int w = 0; w < 16; ++w) if (w < wave) before += wcount[w];
     const int pos = before + __popcll(bm & lanemask_lt());
-    if (k && pos < total) {
+    if (k && pos < total && (long long)s_base + pos < out_rows) {
         const u64 key = s_key[threadIdx.x];
         const uint32_t ord = (uint32_t)key;
         const uint32_t anchor = dh_div(ord, ncd);
@@ -1531,7 +1532,7 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
             size_t workspace_bytes, void* stream)
 {
     if (bs < 0 || bs > 65535 || A < 1 || nc < 1 || max_det < 1 || max_nms < 1 || cap < 1) return DH_ERR_ARG;
-    if ((long long)A * nc >= (1ll << 32)) return DH_ERR_ARG;
+    if ((long long)A * nc >= (1ll << 32) || (long long)bs * max_det >= (1ll << 31)) return DH_ERR_ARG;
     if (bs == 0) return DH_OK;
     if (!out || !out_span || !cand_count || !needs_full || !workspace) return DH_ERR_ARG;
     const nms_layout L = make_layout(bs, cap, max_nms, nc);
@@ -1554,7 +1555,7 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     const float thr = round_down_to_float(iou_thres);
 
     int* cursor = (int*)(ws + L.off_cursor);
-    if (hipMemsetAsync(ws, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;   // every counter's initial state is 0
+    if (dh_fill_async(ws, 0, L.zero_bytes, st) != DH_OK) return DH_ERR_LAUNCH;   // every counter's initial state is 0
     // Multi-label at a validation-style threshold straight from the raw maps: most rows are candidates and there is no
     // compact objectness plane to scan, so the maps are streamed once instead of being visited row by row (measured
     // 163 against 278 us at bs 64).  With a decoded tensor and its plane the row-by-row kernel stays ahead.
@@ -1620,7 +1621,7 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     if (k_select < 0) {      // one workgroup per image does the rest; images with too many candidates set needs_full
         if (max_det > SMALL_MAX) return DH_ERR_ARG;
         const float off = agnostic ? 0.0f : (float)max_wh;
-#define DH_SMALL(R, T) hipLaunchKernelGGL((k_nms_small<R, T>), dim3(bs), dim3(1024), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad, counts, cap, agnostic, off, thr, max_det, out, cursor, (int2*)out_span, cand_count, needs_full)
+#define DH_SMALL(R, T) hipLaunchKernelGGL((k_nms_small<R, T>), dim3(bs), dim3(1024), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad, counts, cap, agnostic, off, thr, max_det, out, cursor, (int2*)out_span, cand_count, needs_full, bs * max_det)
         if (raw && half) DH_SMALL(true, _Float16); else if (raw) DH_SMALL(true, float); else DH_SMALL(false, float);
 #undef DH_SMALL
         return dh_launch_status();
@@ -1659,7 +1660,7 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     }
     hipLaunchKernelGGL(k_nms_collect, dim3(bs), dim3(1024), 0, st, det, keep, ranked, ranked_pad, L.m_cap, counts, m_arr,
                        k_target > 0 ? truncated : (const int*)nullptr, max_det, out, (long long*)nullptr, (int*)nullptr, cursor,
-                       (int2*)out_span, cand_count, needs_full);
+                       (int2*)out_span, cand_count, needs_full, bs * max_det);
     return dh_launch_status();
 }
 
@@ -1870,7 +1871,7 @@ extern "C" int dh_group_nms(const float* rows, const int* first, const int* coun
     if (n_img == 0) return DH_OK;
     if (!first || !count || !out_first || !out_count || !workspace) return DH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (max_rows == 0) return hipMemsetAsync(out_count, 0, sizeof(int) * n_img, st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (max_rows == 0) return dh_fill_async(out_count, 0, sizeof(int) * n_img, st);
     if (!rows || !out) return DH_ERR_ARG;
     const nms_layout L = make_layout(n_img, max_rows, max_rows, nc, false);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
@@ -1885,7 +1886,7 @@ extern "C" int dh_group_nms(const float* rows, const int* first, const int* coun
     u64* keys2 = (u64*)(ws + L.off_keys2);
     float* det = (float*)(ws + L.off_det);
     float4* spill = (float4*)(ws + L.off_spill);
-    if (hipMemsetAsync(ws, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (dh_fill_async(ws, 0, L.zero_bytes, st) != DH_OK) return DH_ERR_LAUNCH;
     const dim3 grid((max_rows + 255) / 256, n_img);
     hipLaunchKernelGGL(k_rows_keys, grid, dim3(256), 0, st, rows, first, count, max_rows, need_nms ? 1 : 0, keys, L.cap_pad, counts);
     hipLaunchKernelGGL(k_sort_keys, dim3(n_img), dim3(SORT_THREADS), 0, st, keys, counts, max_rows, L.cap_pad, (int2*)nullptr, 0,
@@ -1923,7 +1924,7 @@ int nms_plain_run(const float* boxes, const float* scores, int ni, double iou_th
     u64* keys2 = (u64*)(ws + L.off_keys2);
     float* det = (float*)(ws + L.off_det);
     float4* spill = (float4*)(ws + L.off_spill);
-    if (hipMemsetAsync(ws, 0, L.zero_bytes, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (dh_fill_async(ws, 0, L.zero_bytes, st) != DH_OK) return DH_ERR_LAUNCH;
     hipLaunchKernelGGL(k_nms_plain_keys, dim3((ni + 255) / 256), dim3(256), 0, st, scores, ni, keys, counts, m_arr);
     hipLaunchKernelGGL(k_sort_keys, dim3(1), dim3(SORT_THREADS), 0, st, keys, counts, ni, L.cap_pad, (int2*)nullptr, 0,
                        (int*)nullptr, 0);
@@ -1932,7 +1933,7 @@ int nms_plain_run(const float* boxes, const float* scores, int ni, double iou_th
                        (const int2*)nullptr, 1, 0.0f, round_down_to_float(iou_thres), ni, keep, spill);
     hipLaunchKernelGGL(k_nms_collect, dim3(1), dim3(1024), 0, st, det, keep, keys, L.cap_pad, L.m_cap, counts, m_arr,
                        (const int*)nullptr, ni, (float*)nullptr, (long long*)keep_index, keep_count, (int*)nullptr,
-                       (int2*)nullptr, (int*)nullptr, (int*)nullptr);
+                       (int2*)nullptr, (int*)nullptr, (int*)nullptr, ni);
     return dh_launch_status();
 }
 
@@ -1943,7 +1944,7 @@ extern "C" int dh_nms_plain(const float* boxes, const float* scores, int64_t n, 
 {
     if (n < 0 || n >= (1ll << 31) || !keep_count) return DH_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (n == 0) return dh_fill_async(keep_count, 0, sizeof(int), st);
     if (!boxes || !scores || !keep_index || !workspace) return DH_ERR_ARG;
     return nms_plain_run(boxes, scores, (int)n, iou_thres, keep_index, keep_count, workspace, workspace_bytes, st);
 }
@@ -1969,7 +1970,7 @@ extern "C" int dh_nms_plain_noalloc(const float* boxes, const float* scores, int
     if (n < 0 || !keep_count) return DH_ERR_ARG;
     if (n > NOALLOC_MAX_BOXES) return DH_ERR_TOO_LARGE;
     hipStream_t st = (hipStream_t)stream;
-    if (n == 0) return hipMemsetAsync(keep_count, 0, sizeof(int), st) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    if (n == 0) return dh_fill_async(keep_count, 0, sizeof(int), st);
     if (!boxes || !scores || !keep_index) return DH_ERR_ARG;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) return DH_ERR_ARG;

@@ -573,7 +573,7 @@ int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx,
     int* invalid = (int*)(ws + W.off_invalid);
     // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
     // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
-    if (fill && hipMemsetAsync(owner, 0xFF, W.off_iou - W.off_owner, st) != hipSuccess) return DH_ERR_LAUNCH;
+    if (fill && dh_fill_async(owner, 0xFF, W.off_iou - W.off_owner, st) != DH_OK) return DH_ERR_LAUNCH;
     if (P.cap > 0 && (parts & 1)) {
         if (P.conv && P.half) hipLaunchKernelGGL((k_yl_pos_fwd<true, _Float16>), dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
                                                  (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
