@@ -117,9 +117,16 @@ int dh_yolo_head_maps_bwd_f16(const void* const* grad_map_ptrs, void* const* gra
  * the output is the first max_det kept rows in score order and a row's fate depends only on rows ranked above
  * it, so the result is exact whenever that prefix yields max_det rows.  needs_full[b] = 1 marks the images where it
  * did not (their output rows are incomplete): repeat the call with k_select = 0.  With k_select = 0 needs_full is all 0.
- * k_select < 0: everything after the candidate search runs in one workgroup per image (three launches in all, for the
+ * k_select = -1: everything after the candidate search runs in one workgroup per image (three launches in all, for the
  * usual few dozen candidates per image); needs max_det <= 1024, and an image with more than 1024 candidates sets
- * needs_full[b] = 1 and gets no rows: repeat the call with k_select >= 0.
+ * needs_full[b] = 1 and gets no rows: repeat the call with another k_select.
+ * k_select = -2: the best-scoring candidates of an image (the best score bins that together hold at least 3584 keys,
+ * at most 4096) go through sort, box fetch, per-class greedy NMS and collection in one launch, several workgroups per
+ * image, each taking a share of the classes (three launches in all, for the thousands of candidates of validation
+ * thresholds).  needs_full[b] = 1 as for k_select > 0; needs_full[b] = 2 marks an image left to the separate launches
+ * (too many equal scores for the cut, or a box outside the window in which the class offset alone rules out overlap
+ * across classes): repeat with k_select = 3840.  Where its tables do not fit (agnostic, nc > 512, max_det > 448,
+ * A > 2^23) the call runs as k_select = 3840.
  * All of out, out_span, cand_count, needs_full (bs ints), workspace are device memory; workspace must be 256-byte aligned. */
 size_t dh_nms_workspace(int bs, int nc, int cap, int max_nms);
 int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,

@@ -35,6 +35,11 @@ typedef unsigned long long u64;
 
 #define SORT_THREADS 1024
 #define SORT_LDS_KEYS 16384   // 128 KiB of the CU's 160 KiB LDS: one resident sorter per CU
+// Keys sorted in LDS sit at SIDX(i): one unused slot after every 16 keys.  The last pass of every bitonic stage gives a
+// thread 16 consecutive keys; unpadded, the lanes of a wave are then 128 bytes apart and all fall on the same banks (a
+// 32-way conflict on each of the 32 accesses); with the pad the lane stride is 17 keys and the accesses are conflict-free.
+#define SIDX(i) ((i) + ((i) >> 4))
+#define SORT_LDS_SLOTS(n) ((n) + (n) / 16)
 #define KEY_SENTINEL 0xFFFFFFFFFFFFFFFFull
 #define STAGE_KEYS 512
 #define KEPT_LDS 1024
@@ -717,7 +722,7 @@ __device__ __forceinline__ void bitonic_pass(u64* s, uint32_t chunk, uint32_t gb
         const uint32_t base = ((t & ~lowmask) << R) | (t & lowmask);
         u64 v[1 << R];
 #pragma unroll
-        for (int q = 0; q < (1 << R); ++q) v[q] = s[base | ((uint32_t)q << low)];
+        for (int q = 0; q < (1 << R); ++q) v[q] = s[SIDX(base | ((uint32_t)q << low))];
         const bool asc = ((gbase + base) & k) == 0;
 #pragma unroll
         for (int r = R - 1; r >= 0; --r) {
@@ -732,12 +737,12 @@ __device__ __forceinline__ void bitonic_pass(u64* s, uint32_t chunk, uint32_t gb
             }
         }
 #pragma unroll
-        for (int q = 0; q < (1 << R); ++q) s[base | ((uint32_t)q << low)] = v[q];
+        for (int q = 0; q < (1 << R); ++q) s[SIDX(base | ((uint32_t)q << low))] = v[q];
     }
     __syncthreads();
 }
 
-// all (k, j) steps of the bitonic network with j < chunk, on `chunk` keys held in LDS;
+// all (k, j) steps of the bitonic network with j < chunk, on `chunk` keys held in LDS (key i at s[SIDX(i)]);
 // `gbase` is the global position of s[0] (it fixes the direction bits for k > chunk).
 __device__ void bitonic_lds(u64* s, uint32_t chunk, uint32_t gbase, uint32_t k_first, uint32_t k_last)
 {
@@ -753,6 +758,36 @@ __device__ void bitonic_lds(u64* s, uint32_t chunk, uint32_t gbase, uint32_t k_f
     }
 }
 
+// Bitonic sort of npad <= 1024 keys (a power of two, key i at s[SIDX(i)]) by a 1024-thread workgroup, one key per thread
+// in a register: partners less than 64 apart exchange by lane shuffle (no barrier, every wave busy), the others through
+// LDS.  For these sizes the passes of bitonic_lds keep a single wave busy between barriers.
+__device__ void bitonic_small(u64* s, uint32_t npad)
+{
+    const uint32_t t = threadIdx.x;
+    u64 key = t < npad ? s[SIDX(t)] : KEY_SENTINEL;
+    for (uint32_t k = 2; k <= npad; k <<= 1) {
+        const bool asc = (t & k) == 0;
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            u64 other;
+            if (j >= 64) {
+                __syncthreads();
+                if (t < npad) s[SIDX(t)] = key;
+                __syncthreads();
+                other = t < npad ? s[SIDX(t ^ j)] : KEY_SENTINEL;
+            } else {
+                const uint32_t lo = __shfl_xor((uint32_t)key, (int)j, 64), hi = __shfl_xor((uint32_t)(key >> 32), (int)j, 64);
+                other = ((u64)hi << 32) | lo;
+            }
+            const bool low_side = (t & j) == 0;                 // this thread keeps the smaller key of the pair when ascending
+            const bool take_min = low_side == asc;
+            key = take_min ? (other < key ? other : key) : (other > key ? other : key);
+        }
+    }
+    __syncthreads();
+    if (t < npad) s[SIDX(t)] = key;
+    __syncthreads();
+}
+
 __device__ __forceinline__ uint32_t pow2_ceil(uint32_t n)
 {
     uint32_t p = 1;
@@ -761,13 +796,14 @@ __device__ __forceinline__ uint32_t pow2_ceil(uint32_t n)
 }
 
 // first/last position of every class in a sorted [class:32 | rank:32] key array -> seg[class] = {begin, end}
+template <bool PADDED>
 __device__ void write_segments(const u64* k, int n, int2* __restrict__ seg)
 {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t c = (uint32_t)(k[i] >> 32);
+        const uint32_t c = (uint32_t)(k[PADDED ? SIDX(i) : i] >> 32);
         if (i == 0) seg[c].x = 0;
         else {
-            const uint32_t prev = (uint32_t)(k[i - 1] >> 32);
+            const uint32_t prev = (uint32_t)(k[PADDED ? SIDX(i - 1) : i - 1] >> 32);
             if (prev != c) { seg[c].x = i; seg[prev].y = i; }
         }
         if (i == n - 1) seg[c].y = n;
@@ -781,7 +817,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ ke
                                                             int limit, int cap_pad, int2* __restrict__ seg_all, int nc,
                                                             int* __restrict__ m_out, int max_nms)
 {
-    __shared__ u64 s[SORT_LDS_KEYS];
+    __shared__ u64 s[SORT_LDS_SLOTS(SORT_LDS_KEYS)];
     u64* __restrict__ keys = keys_all + (size_t)blockIdx.x * cap_pad;
     int2* __restrict__ seg = seg_all ? seg_all + (size_t)blockIdx.x * nc : nullptr;
     int n = counts[blockIdx.x];
@@ -794,21 +830,21 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ ke
     }
     const uint32_t npad = pow2_ceil((uint32_t)n);
     if (npad <= SORT_LDS_KEYS) {
-        for (uint32_t i = threadIdx.x; i < npad; i += blockDim.x) s[i] = (i < (uint32_t)n) ? keys[i] : KEY_SENTINEL;
+        for (uint32_t i = threadIdx.x; i < npad; i += blockDim.x) s[SIDX(i)] = (i < (uint32_t)n) ? keys[i] : KEY_SENTINEL;
         __syncthreads();
         bitonic_lds(s, npad, 0, 2, npad);
-        for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += blockDim.x) keys[i] = s[i];
-        if (seg) write_segments(s, n, seg);
+        for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += blockDim.x) keys[i] = s[SIDX(i)];
+        if (seg) write_segments<true>(s, n, seg);
         return;
     }
     // larger than LDS: pad in global memory, sort LDS-sized chunks, then merge with global steps + LDS tails
     for (uint32_t i = n + threadIdx.x; i < npad; i += blockDim.x) keys[i] = KEY_SENTINEL;
     __syncthreads();
     for (uint32_t base = 0; base < npad; base += SORT_LDS_KEYS) {
-        for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) s[i] = keys[base + i];
+        for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) s[SIDX(i)] = keys[base + i];
         __syncthreads();
         bitonic_lds(s, SORT_LDS_KEYS, base, 2, SORT_LDS_KEYS);
-        for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) keys[base + i] = s[i];
+        for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) keys[base + i] = s[SIDX(i)];
         __syncthreads();
     }
     for (uint32_t k = 2 * SORT_LDS_KEYS; k <= npad; k <<= 1) {
@@ -823,14 +859,14 @@ __global__ void __launch_bounds__(SORT_THREADS) k_sort_keys(u64* __restrict__ ke
             __syncthreads();   // one workgroup owns the image: its own global writes are visible to it after the barrier
         }
         for (uint32_t base = 0; base < npad; base += SORT_LDS_KEYS) {
-            for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) s[i] = keys[base + i];
+            for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) s[SIDX(i)] = keys[base + i];
             __syncthreads();
             bitonic_lds(s, SORT_LDS_KEYS, base, k, k);
-            for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) keys[base + i] = s[i];
+            for (uint32_t i = threadIdx.x; i < SORT_LDS_KEYS; i += blockDim.x) keys[base + i] = s[SIDX(i)];
             __syncthreads();
         }
     }
-    if (seg) write_segments(keys, n, seg);
+    if (seg) write_segments<false>(keys, n, seg);
 }
 
 // ------------------------------------------------------------------------------------------ 2' select + sort
@@ -847,7 +883,7 @@ __global__ void __launch_bounds__(SORT_THREADS) k_select_sort(const u64* __restr
                                                               u64* __restrict__ top_all, int top_pad,
                                                               int* __restrict__ m_out, int* __restrict__ truncated)
 {
-    __shared__ u64 s[SORT_LDS_KEYS];
+    __shared__ u64 s[SORT_LDS_SLOTS(SORT_LDS_KEYS)];
     __shared__ int hist[SELECT_BINS];
     __shared__ int wsum[SORT_THREADS / 64];
     __shared__ int s_bin, s_below, s_count, s_fill;
@@ -912,17 +948,17 @@ __global__ void __launch_bounds__(SORT_THREADS) k_select_sort(const u64* __restr
             int slot = 0;
             if (lane == 0 && bm) slot = atomicAdd(&s_fill, __popcll(bm));
             slot = __shfl(slot, 0, 64) + __popcll(bm & lanemask_lt());
-            if (take) s[slot] = key;
+            if (take) s[SIDX(slot)] = key;
         }
         __syncthreads();
     } else {
-        for (int i = threadIdx.x; i < n; i += SORT_THREADS) s[i] = keys[i];
+        for (int i = threadIdx.x; i < n; i += SORT_THREADS) s[SIDX(i)] = keys[i];
     }
     const uint32_t npad = pow2_ceil((uint32_t)(T < 2 ? 2 : T));
-    for (uint32_t i = T + threadIdx.x; i < npad; i += SORT_THREADS) s[i] = KEY_SENTINEL;
+    for (uint32_t i = T + threadIdx.x; i < npad; i += SORT_THREADS) s[SIDX(i)] = KEY_SENTINEL;
     __syncthreads();
     bitonic_lds(s, npad, 0, 2, npad);
-    for (int i = threadIdx.x; i < T; i += SORT_THREADS) top[i] = s[i];
+    for (int i = threadIdx.x; i < T; i += SORT_THREADS) top[i] = s[SIDX(i)];
     if (threadIdx.x == 0) {
         m_out[blockIdx.x] = T < max_nms ? T : max_nms;
         truncated[blockIdx.x] = T < n_lim ? 1 : 0;
@@ -1022,14 +1058,29 @@ struct box_t {
 // suppress iff inter/(area_a + area_b - inter) > thr, evaluated exactly as the fp32 reference does;
 // `thr` is the largest float <= the double threshold, which makes the fp32 ">" equal to the
 // reference's comparison in double.  inter == 0 can never exceed a threshold >= 0, so the division
-// is only evaluated for overlapping pairs.
+// is only evaluated for overlapping pairs -- and of those only for the ones a reciprocal cannot decide: inter * rcp(union)
+// is within 3e-7 (relative) of the quotient, so a value more than 1e-6 above or below thr settles the comparison of the
+// correctly rounded quotient as well; the IEEE division (ten instructions) runs for what lies in between, and whenever the
+// operands leave the range where that bound holds.
 __device__ __forceinline__ bool suppresses(const box_t a, float area_a, const box_t b, float area_b, float thr)
 {
     const float w = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.0f);
     const float h = fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.0f);
     const float inter = w * h;
     if (!(inter > 0.0f)) return false;
-    return __fdiv_rn(inter, area_a + area_b - inter) > thr;
+    const float uni = area_a + area_b - inter;
+    if (uni > 1e-30f && uni < 1e30f && inter < 1e30f && thr > 1e-30f) {
+        const float q = inter * __builtin_amdgcn_rcpf(uni);
+        if (q > thr * 1.000001f) return true;
+        if (q < thr * 0.999999f) return false;
+    }
+    return __fdiv_rn(inter, uni) > thr;
+}
+
+// value of `v` in lane `src` (wave-uniform src): a VALU read into a scalar register, no LDS round trip
+__device__ __forceinline__ float lane_value(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
 // WAVES waves per workgroup.  grid = (number of classes or 1, images).
@@ -1230,7 +1281,7 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
                                                     int* __restrict__ cursor, int2* __restrict__ out_span,
                                                     int* __restrict__ cand_count, int* __restrict__ needs_full, int out_rows)
 {
-    __shared__ u64 s_key[SMALL_MAX];
+    __shared__ u64 s_key[SORT_LDS_SLOTS(SMALL_MAX)];      // key i at SIDX(i)
     __shared__ float4 s_box[SMALL_MAX];         // unshifted x1,y1,x2,y2 in score order
     __shared__ float s_off[SMALL_MAX];          // class * max_wh (0 when agnostic)
     __shared__ float4 kbox[SMALL_MAX];          // kept boxes (shifted)
@@ -1251,14 +1302,14 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
     const int n = n_all;
     // sort by score (descending scores are ascending keys)
     const uint32_t npad = pow2_ceil((uint32_t)(n < 2 ? 2 : n));
-    for (uint32_t i = threadIdx.x; i < npad; i += 1024) s_key[i] = (int)i < n ? keys_all[(size_t)b * cap_pad + i] : KEY_SENTINEL;
+    for (uint32_t i = threadIdx.x; i < npad; i += 1024) s_key[SIDX(i)] = (int)i < n ? keys_all[(size_t)b * cap_pad + i] : KEY_SENTINEL;
     s_keep[threadIdx.x] = 0;
     __syncthreads();
     bitonic_lds(s_key, npad, 0, 2, npad);
     // fetch the boxes (general.py:553-560 xywh -> xyxy on the decoded row)
     const int no = (int)ncd.d + 5;
     if ((int)threadIdx.x < n) {
-        const uint32_t ord = (uint32_t)s_key[threadIdx.x];
+        const uint32_t ord = (uint32_t)s_key[SIDX(threadIdx.x)];
         uint32_t anchor = dh_div(ord, ncd);
         const uint32_t cls = ord - anchor * ncd.d;
         if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;      // a key always names a row of the image: never address beyond it
@@ -1351,7 +1402,7 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
     for (int w = 0; w < 16; ++w) if (w < wave) before += wcount[w];
     const int pos = before + __popcll(bm & lanemask_lt());
     if (k && pos < total && (long long)s_base + pos < out_rows) {
-        const u64 key = s_key[threadIdx.x];
+        const u64 key = s_key[SIDX(threadIdx.x)];
         const uint32_t ord = (uint32_t)key;
         const uint32_t anchor = dh_div(ord, ncd);
         const float4 v = s_box[threadIdx.x];
@@ -1359,6 +1410,456 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         o[4] = key_score((uint32_t)(key >> 32));
         o[5] = (float)(ord - anchor * ncd.d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ 2'-6, class groups
+// Validation thresholds leave thousands of candidates per image, of which only a score-ordered prefix can reach the
+// output (see k_select_sort).  Select + sort, gather, class sort, greedy and collect as five launches spend most of their
+// time at launch boundaries, on round trips through global memory for a few thousand rows, and in stages that one
+// workgroup per image runs alone (64 of 256 CUs busy at bs 64).  Class-aware NMS falls apart by class, so this kernel
+// gives an image G workgroups, each responsible for the classes c with c % G == g, and does everything in LDS:
+//   a  every workgroup of the image histograms the scores of ALL its candidates (2048 bins, 128 per octave) and derives the
+//      same cut: the best bins that together hold at least GRP_TARGET keys -- the selected prefix, T <= GRP_MAX keys;
+//   b  it collects the selected keys of its own classes as [class : 9 | score order : 32 | anchor : 23] and sorts them:
+//      every class becomes a contiguous list in score order (equal scores: ascending anchor, the reference's candidate order);
+//   c  it fetches the boxes, runs greedy NMS per list (long lists by the whole workgroup one after another, short ones
+//      by single waves side by side) and appends the kept rows to the image's list in global memory;
+//   d  the workgroup of the image that finishes last picks the first max_det kept rows in score order and writes them.
+// needs_full[b] = 1, as after k_select_sort: the prefix did not yield max_det rows.  needs_full[b] = 2: the image is left
+// to the separate launches (too many equal scores for the cut, more than max_nms keys selected, or a box outside the
+// window in which the class offset alone rules out overlap across classes).
+#define GRP_MAX 4096            // selected keys of an image (all its workgroups together); also what one workgroup's tables hold
+#define GRP_TARGET 3584         // the cut is made where the best bins hold at least this many keys
+#define GRP_BINS 2048
+#define GRP_NC 512              // classes (9 bits of the sort key)
+#define GRP_KEPT 512            // kept list of a list handled by the whole workgroup (>= max_det)
+#define GRP_BIG 192             // class lists longer than this are handled by the whole workgroup
+#define GRP_BIG_LISTS 24        // at most GRP_MAX / GRP_BIG of them (rounded up)
+#define GRP_FINAL 1024          // rows sorted for the output (more candidates for it: the full GRP_MAX sort)
+#define GRP_ANCHOR_BITS 23
+#define GRP_BATCH 8             // key loads a thread keeps in flight while it walks an image's candidates
+
+// Histogram bin of a key: 0 for scores >= 1, then 128 bins per octave going down, the last bin for everything below
+// 2^-16 and for negative scores.  Monotone in the key (ascending key = descending score).
+__device__ __forceinline__ uint32_t score_bin(uint32_t key_hi)
+{
+    const uint32_t e = ~key_hi;
+    if (!(e & 0x80000000u)) return GRP_BINS - 1;
+    const uint32_t sb = e & 0x7FFFFFFFu;
+    if (sb >= 0x3F800000u) return 0;
+    const uint32_t d = (0x3F800000u - sb) >> 16;
+    return d < GRP_BINS - 1 ? d : GRP_BINS - 1;
+}
+
+// Smallest bin B whose cumulative count reaches `need` (or the last bin), and that cumulative count; hist has GRP_BINS
+// entries, all 1024 threads call.  sh: 2 ints of LDS, wsum: 16.
+__device__ void cut_bin(const int* hist, int need, int* wsum, int* sh, int& bin, int& upto)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = hist[2 * threadIdx.x], c1 = hist[2 * threadIdx.x + 1];
+    int incl = c0 + c1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    if (threadIdx.x == 0) { sh[0] = GRP_BINS - 1; sh[1] = -1; }
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    incl += base;
+    const int excl = incl - (c0 + c1);
+    if (excl < need && need <= excl + c0) { sh[0] = 2 * threadIdx.x; sh[1] = excl + c0; }
+    else if (excl + c0 < need && need <= incl) { sh[0] = 2 * threadIdx.x + 1; sh[1] = incl; }
+    __syncthreads();
+    bin = sh[0];
+    upto = sh[1];
+    if (upto < 0) {                       // fewer than `need` keys in all: everything
+        upto = 0;
+        for (int w = 0; w < 16; ++w) upto += wsum[w];
+    }
+    __syncthreads();
+}
+
+template <bool RAW, typename T = float>
+__global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, dh_fastdiv ncd, const u64* __restrict__ keys_all,
+                                                     int cap_pad, const int* __restrict__ counts, int cap, int max_nms, float max_wh,
+                                                     float thr, int max_det, float* __restrict__ kept_all, int m_cap,
+                                                     int* __restrict__ kept_count, int* __restrict__ truncated_out,
+                                                     int* __restrict__ left_flag)
+{
+    __shared__ u64 s_key[SORT_LDS_SLOTS(GRP_MAX)];    // key i at SIDX(i)
+    __shared__ float4 s_box[GRP_MAX];                 // unshifted x1,y1,x2,y2 of the sorted keys
+    __shared__ unsigned char s_keep[GRP_MAX];
+    __shared__ int hist[GRP_BINS];                    // score histogram; then [0,nc) list end, [nc,2nc) list start
+    __shared__ float4 kbox[GRP_KEPT];
+    __shared__ float karea[GRP_KEPT];
+    __shared__ u64 sup_mask[16], cmask[64];
+    __shared__ float4 cbox[64];
+    __shared__ float carea[64];
+    __shared__ int wsum[16], sh[4], s_big[GRP_BIG_LISTS], s_nbig, s_next, s_kept, s_base, s_fill, s_bad;
+    const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc = (int)ncd.d;
+    const int n_all = counts[b];
+    const int n = n_all > cap ? cap : n_all;
+    const u64* __restrict__ keys = keys_all + (size_t)b * cap_pad;
+    float* __restrict__ kept_rows = kept_all + (size_t)b * m_cap * 6;      // {score order, anchor*nc + class, x1, y1, x2, y2} per kept row
+    const int n_lim = n < max_nms ? n : max_nms;                          // general.py:716-717
+    int ns = 0;                  // selected keys of this workgroup's classes
+    int Tn = n;                  // selected keys of the image
+    bool left = false;           // leave the image to the separate launches
+    if (n > 0) {
+        // a: the cut
+        int cut = GRP_BINS - 1;
+        if (n > GRP_MAX) {
+            for (int i = threadIdx.x; i < GRP_BINS; i += 1024) hist[i] = 0;
+            __syncthreads();
+            for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * GRP_BATCH) {      // GRP_BATCH loads in flight per thread
+                u64 kk[GRP_BATCH];
+#pragma unroll
+                for (int u = 0; u < GRP_BATCH; ++u) kk[u] = i0 + 1024 * u < n ? keys[i0 + 1024 * u] : 0;
+#pragma unroll
+                for (int u = 0; u < GRP_BATCH; ++u)
+                    if (i0 + 1024 * u < n) atomicAdd(&hist[score_bin((uint32_t)(kk[u] >> 32))], 1);
+            }
+            __syncthreads();
+            cut_bin(hist, GRP_TARGET, wsum, sh, cut, Tn);
+            left = Tn > GRP_MAX || Tn > max_nms;
+        } else {
+            left = n > max_nms;
+        }
+        // b: this workgroup's share of the selected keys, sorted by (class, score order, anchor)
+        if (threadIdx.x == 0) { s_fill = 0; s_next = 0; s_bad = 0; }
+        for (int i = threadIdx.x; i < GRP_MAX; i += 1024) s_keep[i] = 0;
+        for (int i = threadIdx.x; i < 2 * nc; i += 1024) hist[i] = 0;
+        __syncthreads();
+        if (!left) {
+            for (int i0 = threadIdx.x; i0 < n; i0 += 1024 * GRP_BATCH) {
+                u64 kk[GRP_BATCH];
+#pragma unroll
+                for (int u = 0; u < GRP_BATCH; ++u) kk[u] = i0 + 1024 * u < n ? keys[i0 + 1024 * u] : 0;
+#pragma unroll
+                for (int u = 0; u < GRP_BATCH; ++u) {
+                    const u64 key = kk[u];
+                    const uint32_t ord = (uint32_t)key;
+                    const uint32_t anchor = dh_div(ord, ncd);
+                    const uint32_t cls = ord - anchor * ncd.d;
+                    const bool take = i0 + 1024 * u < n && (int)score_bin((uint32_t)(key >> 32)) <= cut && (int)(cls % (uint32_t)G) == g;
+                    const u64 ck = ((u64)cls << 55) | ((key >> 32) << GRP_ANCHOR_BITS) | (u64)(anchor & ((1u << GRP_ANCHOR_BITS) - 1u));
+                    const u64 bm = __ballot(take);
+                    if (bm == 0) continue;                              // wave-uniform
+                    int slot = 0;
+                    if (lane == 0) slot = atomicAdd(&s_fill, __popcll(bm));
+                    slot = __builtin_amdgcn_readfirstlane(slot) + __popcll(bm & lanemask_lt());
+                    if (take && slot < GRP_MAX) s_key[SIDX(slot)] = ck;
+                }
+            }
+            __syncthreads();
+            ns = s_fill < GRP_MAX ? s_fill : GRP_MAX;         // s_fill <= Tn <= GRP_MAX
+        }
+    }
+    const bool truncated = Tn < n_lim;
+    if (ns > 0) {
+        const uint32_t npad = pow2_ceil((uint32_t)(ns < 2 ? 2 : ns));
+        for (uint32_t i = ns + threadIdx.x; i < npad; i += 1024) s_key[SIDX(i)] = KEY_SENTINEL;
+        __syncthreads();
+        if (npad <= 1024) bitonic_small(s_key, npad); else bitonic_lds(s_key, npad, 0, 2, npad);
+        // c: boxes (general.py:553-560 on the decoded row), list boundaries
+        const int no = nc + 5;
+        // every coordinate inside this window: boxes of different classes cannot overlap once shifted by class * max_wh
+        const float win = 0.5f * (max_wh - 1.0f);
+        bool bad = false;
+        for (int i = threadIdx.x; i < ns; i += 1024) {
+            const u64 ck = s_key[SIDX(i)];
+            const int cls = (int)(ck >> 55);
+            uint32_t anchor = (uint32_t)ck & ((1u << GRP_ANCHOR_BITS) - 1u);
+            if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;
+            float x, y, w, h;
+            if (RAW) {
+                const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
+                const decode_level& L = S.lvl[rr.l];
+                x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
+                y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
+                w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
+                h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
+            } else {
+                const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
+                x = p[0]; y = p[1]; w = p[2]; h = p[3];
+            }
+            const float x1 = x - w / 2, y1 = y - h / 2, x2 = x + w / 2, y2 = y + h / 2;
+            s_box[i] = make_float4(x1, y1, x2, y2);
+            bad = bad || !(fabsf(x1) < win && fabsf(y1) < win && fabsf(x2) < win && fabsf(y2) < win);
+            if (cls < nc) {
+                if (i == 0 || (int)(s_key[SIDX(i - 1)] >> 55) != cls) hist[nc + cls] = i;
+                if (i == ns - 1 || (int)(s_key[SIDX(i + 1)] >> 55) != cls) hist[cls] = i + 1;
+            }
+        }
+        if (__ballot(bad) != 0 && lane == 0) s_bad = 1;
+        __syncthreads();
+        left = left || s_bad != 0;
+        if (!left) {
+            // lists the whole workgroup handles
+            if (wave == 0) {
+                int nbig_run = 0;                                       // wave-uniform
+                for (int c0 = 0; c0 < nc; c0 += 64) {
+                    const int c = c0 + lane;
+                    const int len = c < nc ? hist[c] - hist[nc + c] : 0;
+                    const u64 bigm = __ballot(len > GRP_BIG);
+                    if (len > GRP_BIG) {
+                        const int at = nbig_run + __popcll(bigm & lanemask_lt());
+                        if (at < GRP_BIG_LISTS) s_big[at] = c;
+                    }
+                    nbig_run += __popcll(bigm);
+                }
+                if (lane == 0) s_nbig = nbig_run < GRP_BIG_LISTS ? nbig_run : GRP_BIG_LISTS;
+            }
+            __syncthreads();
+            // greedy NMS, long lists: the whole workgroup, 64 candidates at a time (the scheme of k_nms_small)
+            const int nbig = s_nbig;
+            for (int q = 0; q < nbig; ++q) {
+                const int c = s_big[q];
+                const int start = hist[nc + c], len = hist[c] - start;
+                const float off = (float)c * max_wh;                    // general.py:720
+                int kept = 0;
+                for (int base = 0; base < len && kept < max_det; base += 64) {
+                    const int p = base + lane;
+                    const bool valid = p < len;
+                    box_t bx = {0.f, 0.f, 0.f, 0.f};
+                    if (valid) {
+                        const float4 v = s_box[start + p];
+                        bx.x1 = v.x + off; bx.y1 = v.y + off; bx.x2 = v.z + off; bx.y2 = v.w + off;     // general.py:721
+                    }
+                    const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
+                    bool sup = false;
+                    for (int k = wave; k < kept; k += 16) {
+                        const float4 kb = kbox[k];
+                        const box_t kbb = {kb.x, kb.y, kb.z, kb.w};
+                        sup = sup || suppresses(kbb, karea[k], bx, area, thr);
+                    }
+                    const u64 sm = __ballot(sup);
+                    if (lane == 0) sup_mask[wave] = sm;
+                    if (wave == 0) { cbox[lane] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2); carea[lane] = area; }
+                    __syncthreads();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int i = wave * 4 + t;
+                        const float4 bi4 = cbox[i];
+                        const box_t bi = {bi4.x, bi4.y, bi4.z, bi4.w};
+                        const bool hit = (lane > i) && suppresses(bi, carea[i], bx, area, thr);
+                        const u64 hm = __ballot(hit);
+                        if (lane == 0) cmask[i] = hm;
+                    }
+                    __syncthreads();
+                    if (wave == 0) {
+                        u64 dead = 0;
+#pragma unroll
+                        for (int w = 0; w < 16; ++w) dead |= sup_mask[w];
+                        u64 todo = __ballot(valid) & ~dead;
+                        u64 kept_mask = 0;
+                        int room = max_det - kept;
+                        while (todo && room > 0) {
+                            const int i = __ffsll((long long)todo) - 1;
+                            kept_mask |= 1ull << i;
+                            todo &= ~(cmask[i] | (1ull << i));
+                            --room;
+                        }
+                        if ((kept_mask >> lane) & 1ull) {
+                            const int slot = kept + __popcll(kept_mask & lanemask_lt());
+                            s_keep[start + p] = 1;
+                            kbox[slot] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2);
+                            karea[slot] = area;
+                        }
+                        if (lane == 0) s_kept = kept + __popcll(kept_mask);
+                    }
+                    __syncthreads();
+                    kept = s_kept;
+                }
+            }
+            // short lists: one wave each, taken from a common counter; earlier kept boxes are found through the kept
+            // masks of the list's earlier chunks (at most GRP_BIG / 64 of them)
+            for (;;) {
+                int ci = 0;
+                if (lane == 0) ci = atomicAdd(&s_next, 1);
+                const int c = g + __builtin_amdgcn_readfirstlane(ci) * G;
+                if (c >= nc) break;
+                const int start = hist[nc + c], len = hist[c] - start;
+                if (len <= 0 || len > GRP_BIG) continue;
+                const float off = (float)c * max_wh;                    // general.py:720
+                u64 keptm[GRP_BIG / 64];
+                int kept = 0;
+#pragma unroll
+                for (int j = 0; j < GRP_BIG / 64; ++j) {
+                    keptm[j] = 0;
+                    if (64 * j >= len || kept >= max_det) continue;     // wave-uniform
+                    const int p = 64 * j + lane;
+                    const bool valid = p < len;
+                    box_t bx = {0.f, 0.f, 0.f, 0.f};
+                    if (valid) {
+                        const float4 v = s_box[start + p];
+                        bx.x1 = v.x + off; bx.y1 = v.y + off; bx.x2 = v.z + off; bx.y2 = v.w + off;     // general.py:721
+                    }
+                    const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
+                    bool sup = false;
+#pragma unroll
+                    for (int pj = 0; pj < j; ++pj) {
+                        u64 km = keptm[pj];
+                        while (km) {
+                            const int i = __ffsll((long long)km) - 1;
+                            km &= km - 1;
+                            const float4 v = s_box[start + 64 * pj + i];
+                            const box_t kb = {v.x + off, v.y + off, v.z + off, v.w + off};
+                            sup = sup || suppresses(kb, (kb.x2 - kb.x1) * (kb.y2 - kb.y1), bx, area, thr);
+                        }
+                    }
+                    u64 todo = __ballot(valid && !sup);
+                    u64 kept_mask = 0;
+                    int room = max_det - kept;
+                    while (todo && room > 0) {
+                        const int i = __ffsll((long long)todo) - 1;
+                        kept_mask |= 1ull << i;
+                        const box_t bi = {lane_value(bx.x1, i), lane_value(bx.y1, i), lane_value(bx.x2, i), lane_value(bx.y2, i)};
+                        const float ai = lane_value(area, i);
+                        const bool hit = (lane > i) && suppresses(bi, ai, bx, area, thr);
+                        todo &= ~(__ballot(hit) | (1ull << i));
+                        --room;
+                    }
+                    keptm[j] = kept_mask;
+                    if ((kept_mask >> lane) & 1ull) s_keep[start + p] = 1;
+                    kept += __popcll(kept_mask);
+                }
+            }
+            __syncthreads();
+            // the kept rows join the image's list (any order: the last workgroup sorts what it needs)
+            for (int base = 0; base < ns; base += 1024) {
+                const int i = base + threadIdx.x;
+                const bool k = i < ns && s_keep[i] != 0;
+                const u64 bm = __ballot(k);
+                if (lane == 0) wsum[wave] = __popcll(bm);
+                __syncthreads();
+                int before = 0, all = 0;
+#pragma unroll
+                for (int w = 0; w < 16; ++w) { const int cw = wsum[w]; if (w < wave) before += cw; all += cw; }
+                if (threadIdx.x == 0) s_base = all ? atomicAdd(&kept_count[b], all) : 0;
+                __syncthreads();
+                const int at = s_base + before + __popcll(bm & lanemask_lt());
+                if (k && at < m_cap) {
+                    const u64 ck = s_key[SIDX(i)];
+                    const uint32_t cls = (uint32_t)(ck >> 55), anchor = (uint32_t)ck & ((1u << GRP_ANCHOR_BITS) - 1u);
+                    const float4 v = s_box[i];
+                    float* __restrict__ o = kept_rows + (size_t)at * 6;
+                    o[0] = __uint_as_float((uint32_t)(ck >> GRP_ANCHOR_BITS));
+                    o[1] = __uint_as_float(anchor * ncd.d + cls);
+                    o[2] = v.x; o[3] = v.y; o[4] = v.z; o[5] = v.w;
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (left) atomicOr(&left_flag[b], 1);
+        if (g == 0) truncated_out[b] = truncated ? 1 : 0;
+    }
+}
+
+// d  One workgroup per image: the first max_det kept rows in score order, from the list the class groups appended to.
+__global__ void __launch_bounds__(1024) k_nms_groups_final(dh_fastdiv ncd, const float* __restrict__ kept_all, int m_cap,
+                                                           const int* __restrict__ counts, const int* __restrict__ kept_count,
+                                                           const int* __restrict__ truncated_in, const int* __restrict__ left_flag,
+                                                           int max_det, float* __restrict__ out, int* __restrict__ cursor,
+                                                           int2* __restrict__ out_span, int* __restrict__ cand_count,
+                                                           int* __restrict__ needs_full, int out_rows)
+{
+    __shared__ u64 s_key[SORT_LDS_SLOTS(GRP_MAX)];    // key i at SIDX(i)
+    __shared__ int hist[GRP_BINS];
+    __shared__ int wsum[16], sh[4], s_fill, s_base;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const float* __restrict__ kept_rows = kept_all + (size_t)b * m_cap * 6;
+    if (threadIdx.x == 0) cand_count[b] = counts[b];
+    const int is_left = left_flag[b];
+    const bool truncated = truncated_in[b] != 0;
+    int K = kept_count[b];
+    if (K > m_cap) K = m_cap;
+    if (K > GRP_MAX) K = GRP_MAX;
+    if (is_left || K <= 0) {                                            // workgroup-uniform
+        if (threadIdx.x == 0) { out_span[b] = make_int2(0, 0); needs_full[b] = is_left ? 2 : (truncated ? 1 : 0); }
+        return;
+    }
+    const int total = K < max_det ? K : max_det;
+    // this thread's kept rows: {score order, anchor*nc + class} of row j, GRP_MAX / 1024 of them at most
+    u64 mykey[GRP_MAX / 1024];
+#pragma unroll
+    for (int u = 0; u < GRP_MAX / 1024; ++u) {
+        const int j = threadIdx.x + 1024 * u;
+        mykey[u] = KEY_SENTINEL;
+        if (j < K) {
+            const float* __restrict__ r = kept_rows + (size_t)j * 6;
+            mykey[u] = ((u64)__float_as_uint(r[0]) << 32) | __float_as_uint(r[1]);
+        }
+    }
+    // candidates for the output: the best bins of the kept rows' scores that hold at least `total` rows
+    int cutK = GRP_BINS - 1, nsel = K;
+    if (K > GRP_FINAL) {
+        for (int i = threadIdx.x; i < GRP_BINS; i += 1024) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < GRP_MAX / 1024; ++u)
+            if (threadIdx.x + 1024 * u < K) atomicAdd(&hist[score_bin((uint32_t)(mykey[u] >> 32))], 1);
+        __syncthreads();
+        cut_bin(hist, total, wsum, sh, cutK, nsel);
+    }
+    if (threadIdx.x == 0) s_fill = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < GRP_MAX / 1024; ++u) {
+        const bool take = threadIdx.x + 1024 * u < K && (int)score_bin((uint32_t)(mykey[u] >> 32)) <= cutK;
+        const u64 bm = __ballot(take);
+        if (bm == 0) continue;                                          // wave-uniform
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&s_fill, __popcll(bm));
+        slot = __builtin_amdgcn_readfirstlane(slot) + __popcll(bm & lanemask_lt());
+        if (take && slot < GRP_MAX) s_key[SIDX(slot)] = mykey[u];
+    }
+    __syncthreads();
+    nsel = s_fill < GRP_MAX ? s_fill : GRP_MAX;
+    {
+        const uint32_t npad = pow2_ceil((uint32_t)(nsel < 2 ? 2 : nsel));
+        for (uint32_t i = nsel + threadIdx.x; i < npad; i += 1024) s_key[SIDX(i)] = KEY_SENTINEL;
+        __syncthreads();
+        if (npad <= 1024) bitonic_small(s_key, npad); else bitonic_lds(s_key, npad, 0, 2, npad);
+    }
+    if (threadIdx.x == 0) {
+        needs_full[b] = (truncated && K < max_det) ? 1 : 0;
+        const int first = atomicAdd(cursor, total);
+        s_base = first;
+        out_span[b] = make_int2(first, total);
+    }
+    __syncthreads();
+    const int first = s_base;
+    // every kept row looks its rank up in the sorted keys (they are all different) and, if it is among the first
+    // `total`, writes its row there
+#pragma unroll
+    for (int u = 0; u < GRP_MAX / 1024; ++u) {
+        const int j = threadIdx.x + 1024 * u;
+        const u64 key = mykey[u];
+        if (j >= K || (int)score_bin((uint32_t)(key >> 32)) > cutK) continue;
+        int lo = 0, hi = nsel;                      // first position with s_key >= key
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_key[SIDX(mid)] < key) lo = mid + 1; else hi = mid;
+        }
+        if (lo < total && (long long)first + lo < out_rows) {
+            const float* __restrict__ r = kept_rows + (size_t)j * 6;
+            const uint32_t ord = (uint32_t)key;
+            const uint32_t anchor = dh_div(ord, ncd);
+            float* __restrict__ o = out + ((size_t)first + lo) * 6;
+            o[0] = r[2]; o[1] = r[3]; o[2] = r[4]; o[3] = r[5];
+            o[4] = key_score((uint32_t)(key >> 32));
+            o[5] = (float)(ord - anchor * ncd.d);
+        }
     }
 }
 
@@ -1458,7 +1959,7 @@ __global__ void __launch_bounds__(256) k_nms_plain_gather(const float* __restric
 
 struct nms_layout {
     int cap_pad, m_cap, m_pad;
-    size_t off_counts, off_m, off_trunc, off_range, off_cursor, off_seg, off_keys, off_top, off_keys2, off_det, off_keep, off_spill, total;
+    size_t off_counts, off_m, off_trunc, off_flag, off_range, off_cursor, off_seg, off_keys, off_top, off_keys2, off_det, off_keep, off_spill, total;
     int top_pad;         // keys per image in the select-sort output (0: selection not used)
     size_t zero_bytes;   // [0, zero_bytes) = counts, ranges, cursor, segment table, keep flags: cleared by one memset
 };
@@ -1494,6 +1995,7 @@ nms_layout make_layout(int bs, int cap, int max_nms, int nc, bool with_top = tru
     L.off_counts = o; o = align_up(o + sizeof(int) * bs, 256);
     L.off_m = o; o = align_up(o + sizeof(int) * bs, 256);
     L.off_trunc = o; o = align_up(o + sizeof(int) * bs, 256);
+    L.off_flag = o; o = align_up(o + sizeof(int) * bs, 256);
     L.off_range = o; o = align_up(o + sizeof(img_range) * bs, 256);
     L.off_cursor = o; o = align_up(o + sizeof(int), 256);
     L.off_seg = o; o = align_up(o + sizeof(int2) * (size_t)bs * nc, 256);
@@ -1536,6 +2038,12 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     if (bs == 0) return DH_OK;
     if (!out || !out_span || !cand_count || !needs_full || !workspace) return DH_ERR_ARG;
     const nms_layout L = make_layout(bs, cap, max_nms, nc);
+    // k_select = -2: everything after the candidate search in one launch (k_nms_groups) where its tables fit; otherwise
+    // the same kind of score prefix goes through the separate launches
+    const bool chain = k_select == -2 && !agnostic && max_wh >= 0.0 && nc <= GRP_NC && max_det <= GRP_KEPT &&
+                       8l * max_det <= GRP_TARGET && A <= (1 << GRP_ANCHOR_BITS);
+    if (k_select == -2 && !chain) k_select = GRP_MAX - 256;
+    if (k_select < -2) return DH_ERR_ARG;
     const int k_target = select_target(k_select, max_det, cap, max_nms);
     if (workspace_bytes < L.total) return DH_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
@@ -1618,7 +2126,21 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     else { if (raw) DH_PREFILTER_N(false, true, float); else DH_PREFILTER_N(false, false, float); }
 #undef DH_PREFILTER_N
 #undef DH_PREFILTER
-    if (k_select < 0) {      // one workgroup per image does the rest; images with too many candidates set needs_full
+    if (chain) {
+        // G workgroups per image, each taking the classes c % G == g: enough of them to fill the chip
+        int G = 256 / bs;
+        G = G < 1 ? 1 : (G > 16 ? 16 : G);
+        if (G > nc) G = nc;
+        int* kept_count = m_arr;                                        // zero after the fill above
+        int* left_flag = (int*)(ws + L.off_flag);
+#define DH_GROUPS(R, T) hipLaunchKernelGGL((k_nms_groups<R, T>), dim3(G, bs), dim3(1024), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad, counts, cap, max_nms, (float)max_wh, thr, max_det, det, L.m_cap, kept_count, truncated, left_flag)
+        if (raw && half) DH_GROUPS(true, _Float16); else if (raw) DH_GROUPS(true, float); else DH_GROUPS(false, float);
+#undef DH_GROUPS
+        hipLaunchKernelGGL(k_nms_groups_final, dim3(bs), dim3(1024), 0, st, dh_make_fastdiv((uint32_t)nc), det, L.m_cap, counts, kept_count,
+                           truncated, left_flag, max_det, out, cursor, (int2*)out_span, cand_count, needs_full, bs * max_det);
+        return dh_launch_status();
+    }
+    if (k_select == -1) {      // one workgroup per image does the rest; images with too many candidates set needs_full
         if (max_det > SMALL_MAX) return DH_ERR_ARG;
         const float off = agnostic ? 0.0f : (float)max_wh;
 #define DH_SMALL(R, T) hipLaunchKernelGGL((k_nms_small<R, T>), dim3(bs), dim3(1024), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad, counts, cap, agnostic, off, thr, max_det, out, cursor, (int2*)out_span, cand_count, needs_full, bs * max_det)

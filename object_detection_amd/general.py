@@ -10,6 +10,7 @@ MAX_WH = 7680      # general.py:663
 MAX_NMS = 30000    # general.py:664
 K_SELECT = 3840    # candidates per image that go through NMS on the first attempt (0: all); see nms_launch
 K_SMALL = -1       # k_select value: everything after the prefilter in one workgroup per image (<= SMALL_MAX candidates each)
+K_CHAIN = -2       # k_select value: a prefix of about K_SELECT candidates, everything after the prefilter in one launch (class groups)
 SMALL_MAX = 1024   # what that workgroup holds (SMALL_MAX of csrc/nms.hip)
 SMALL_BELOW = 768  # candidate count of the busiest image up to which the next call of the same kind tries the small path
 
@@ -22,16 +23,23 @@ _SMALL_HINT = {}
 def _first_attempt(key, max_det, k_select):
     if k_select is not None:
         return int(k_select)
-    return K_SMALL if (max_det <= SMALL_MAX and _SMALL_HINT.get(key, False)) else K_SELECT
+    return K_SMALL if (max_det <= SMALL_MAX and _SMALL_HINT.get(key, False)) else K_CHAIN
 
 
 def _remember(rows, key, used):
     rows._dh_attempt = (key, used)          # read back by nms_views, which sees the candidate counts
 
 
-def _next_attempt(rows):
-    """After needs_full: the small attempt is followed by the prefix selection, that one by the full sort."""
-    return K_SELECT if getattr(rows, "_dh_attempt", (None, 0))[1] < 0 else 0
+def _next_attempt(rows, need=-1):
+    """After needs_full: the small attempt is followed by the prefix selection in one launch (class groups); that one by a
+    prefix through the separate launches when some image was left to them (need = -2: a box far outside the image, too
+    many equal scores), else -- like the separate launches themselves -- by the full sort."""
+    used = getattr(rows, "_dh_attempt", (None, 0))[1]
+    if used == K_SMALL:
+        return K_CHAIN
+    if used == K_CHAIN and need == -2:
+        return K_SELECT
+    return 0
 
 
 def _convert(x, mode):
@@ -133,8 +141,11 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     through NMS, which is exact whenever they yield max_det rows (a row's fate depends only on rows ranked above
     it); images where they do not are flagged in meta and nms_views asks for a repeat with k_select=0.
     k_select = K_SMALL: one workgroup per image does everything after the prefilter (three launches instead of
-    seven); images with more than SMALL_MAX candidates are flagged the same way.  k_select = None picks K_SMALL
-    when the last call of the same kind stayed below SMALL_BELOW candidates per image, K_SELECT otherwise.
+    seven); images with more than SMALL_MAX candidates are flagged the same way.  k_select = K_CHAIN: about K_SELECT
+    of the best candidates of each image go through sort, box fetch, per-class greedy NMS and collection in one
+    launch (several workgroups per image, each with a share of the classes, LDS resident); images it leaves to the
+    separate launches are flagged 2.  k_select = None picks K_SMALL
+    when the last call of the same kind stayed below SMALL_BELOW candidates per image, K_CHAIN otherwise.
     merge: merge-NMS (general.py:725-731) on the result; it needs every candidate, so the general path runs (k_select=0).
     """
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
@@ -251,10 +262,16 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
 
 
 def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-               max_det=300, merge=False):
+               labels=(), max_det=300, merge=False):
     """non_max_suppression(Detect(x)[0], ...) (val.py:194,203; detect.py:126,132) straight from the raw head maps
     `levels` (list of (bs,na,ny,nx,5+nc)); anchors / stride as Detect holds them.  Bit-identical to the two-call
-    sequence, at about half its HBM traffic: the decoded (bs, A, 5+nc) tensor is neither written nor read."""
+    sequence, at about half its HBM traffic: the decoded (bs, A, 5+nc) tensor is neither written nor read.
+    labels: a-priori label rows per image (general.py:678-684, the auto-labelling mode of val.py:203).  They join the
+    candidates as rows of the decoded tensor, so with labels the decoded tensor is made and the two-call sequence runs."""
+    if labels is not None and len(labels) and any(len(l) for l in labels):
+        from .yolo import detect_decode
+        return non_max_suppression(detect_decode(levels, anchors, stride), conf_thres, iou_thres, classes, agnostic, multi_label,
+                                   labels, max_det, merge)
     cap, k_select = None, None
     while True:
         rows, meta, cap = detect_nms_launch(levels, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
@@ -265,17 +282,22 @@ def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes
         if result is not None:
             return result
         if need < 0:
-            k_select = _next_attempt(rows)
+            k_select = _next_attempt(rows, need)
         else:
             cap = need
 
 
 def conv_nms(convs, na, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-             max_det=300, merge=False):
+             labels=(), max_det=300, merge=False):
     """non_max_suppression(Detect(x)[0], ...) (detect.py:126,132; val.py:194,203 without compute_loss) straight from the
     outputs of Detect's 1x1 convolutions, `convs` = list of (bs, na*no, ny, nx): what Detect.forward holds before the
     layout change of yolo.py:54.  Neither the head maps nor the decoded tensor are written or read; the detections are
-    bit-identical to non_max_suppression(head_maps_decode(convs, ...)[0], ...)."""
+    bit-identical to non_max_suppression(head_maps_decode(convs, ...)[0], ...).
+    labels: as for detect_nms (with labels the decoded tensor is made: head_maps_decode, then non_max_suppression)."""
+    if labels is not None and len(labels) and any(len(l) for l in labels):
+        from .yolo import head_maps_decode
+        return non_max_suppression(head_maps_decode(convs, na, anchors, stride, lazy=True)[0], conf_thres, iou_thres, classes,
+                                   agnostic, multi_label, labels, max_det, merge)
     cap, k_select = None, None
     while True:
         rows, meta, cap = detect_nms_launch(convs, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
@@ -286,7 +308,7 @@ def conv_nms(convs, na, anchors, stride, conf_thres=0.25, iou_thres=0.45, classe
         if result is not None:
             return result
         if need < 0:
-            k_select = _next_attempt(rows)
+            k_select = _next_attempt(rows, need)
         else:
             cap = need
 
@@ -308,8 +330,9 @@ def nms_meta_to_host(meta, pinned=None):
 def nms_views(rows, host, cap):
     """Per-image (k,6) views of the packed rows from the host copy of meta.
 
-    (None, needed_cap) when the candidate capacity overflowed, (None, -1) when some image needs the full sort
-    (see nms_launch): the caller repeats the launch with that cap, or with k_select=0."""
+    (None, needed_cap) when the candidate capacity overflowed, (None, -1) when some image needs the full sort,
+    (None, -2) when some image needs the separate launches (see nms_launch, _next_attempt): the caller repeats the
+    launch with that cap, or with the next k_select."""
     bs = len(host) // 4
     busiest = max(host[2 * bs:3 * bs])
     key = getattr(rows, "_dh_attempt", (None, 0))[0]
@@ -319,8 +342,9 @@ def nms_views(rows, host, cap):
         _SMALL_HINT[key] = busiest <= SMALL_BELOW
     if busiest > cap:
         return None, busiest
-    if any(host[3 * bs:]):
-        return None, -1
+    flags = host[3 * bs:]
+    if any(flags):
+        return None, (-1 if 1 in flags else -2)
     # images are packed in completion order: one split() call makes every per-image view
     first, count = host[0:2 * bs:2], host[1:2 * bs:2]
     order = [i for i in sorted(range(bs), key=first.__getitem__) if count[i]]
@@ -365,6 +389,6 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         if result is not None:
             return result
         if need < 0:
-            k_select = _next_attempt(rows)      # the attempt did not cover some image: the next, more general one
+            k_select = _next_attempt(rows, need)      # the attempt did not cover some image: the next, more general one
         else:
             cap = need        # multi-label produced more candidates than rows: rerun with room for all of them

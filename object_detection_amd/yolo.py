@@ -261,7 +261,8 @@ class Detect(nn.Module):
         self.m = nn.ModuleList(nn.Conv2d(x, self.no * self.na, 1) for x in ch)
         self.inplace = inplace
 
-    def detections(self, x, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, max_det=300):
+    def detections(self, x, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, labels=(),
+                   max_det=300):
         """non_max_suppression(self(x)[0], ...) for callers that want nothing else from the head (detect.py:126-132,
         val.py:194-203 without compute_loss): the convolutions run as in forward, the detections come straight from
         their outputs; neither the head maps nor the decoded tensor are made.  Same rows as the two calls, bit for bit."""
@@ -269,7 +270,7 @@ class Detect(nn.Module):
         with torch.no_grad():
             convs = [self.m[i](x[i]) for i in range(self.nl)]
             return conv_nms(convs, self.na, self.anchors, self.stride, conf_thres, iou_thres, classes, agnostic, multi_label,
-                            max_det)
+                            labels, max_det)
 
     def _make_grid(self, nx=20, ny=20, i=0):
         """yolo.py:72-81: cell indices (x, y) and anchors in pixels, both (1, na, ny, nx, 2).  The decode kernel derives

@@ -377,8 +377,8 @@ class ComputeLoss:
         the assigned rows, which read only the targets and the raw maps.  Enqueue it on a side stream beside whatever
         produces or decodes `p`, make the main stream wait for it (an event), and hand the result to
         forward_backward(..., positives=...), which then only runs the dense objectness pass and the backward."""
-        if self.sort_obj_iou or self.autobalance:
-            raise NotImplementedError("positives / forward_backward support neither sort_obj_iou nor autobalance")
+        if self.sort_obj_iou:
+            raise NotImplementedError("sort_obj_iou=True is not supported (the reference never enables it, loss.py:94)")
         maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
         shapes = [(int(x.shape[2]), int(x.shape[3])) for x in maps]
         return _loss_positives(shapes, targets, self.anchors, self.hyp['anchor_t'], self._hyp_struct(), int(self.nc), maps)
@@ -390,8 +390,8 @@ class ComputeLoss:
         the device, default 1) is the upstream gradient of the loss.  Everything stays on the calling stream with no
         host synchronisation and no hop to the autograd engine's device thread.
         """
-        if self.sort_obj_iou or self.autobalance:
-            raise NotImplementedError("forward_backward supports neither sort_obj_iou nor autobalance")
+        if self.sort_obj_iou:
+            raise NotImplementedError("sort_obj_iou=True is not supported (the reference never enables it, loss.py:94)")
         convs = conv_layout_of(p) if assignment is None and positives is None else None
         if convs is not None:       # lazy maps (see conv_layout_of): gradients come back as views of the same kind
             shapes = [(int(x.shape[2]), int(x.shape[3])) for x in p]
@@ -400,6 +400,7 @@ class ComputeLoss:
                                              [c.detach() for c in convs], g.reshape(1).float().contiguous(), conv=True)
             self.last_positive_counts = assign.counts
             self.last_stats = out[1:5]
+            self._autobalance_step(out)
             return out[0:1], out[1:4], _as_map_views(grads, int(p[0].shape[1]))
         maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
         shapes = [(int(x.shape[2]), int(x.shape[3])) for x in maps]
@@ -418,7 +419,16 @@ class ComputeLoss:
             assign, out, grads = _loss_fused(shapes, targets, self.anchors, self.hyp['anchor_t'], hyp, int(self.nc), maps, grad_loss)
         self.last_positive_counts = assign.counts
         self.last_stats = out[1:5]
+        self._autobalance_step(out)
         return out[0:1], out[1:4], grads
+
+    def _autobalance_step(self, out):
+        """loss.py:157-161: the balance weights follow the per-level objectness means (one host round trip, like the
+        reference's .item()); out = [loss, lbox, lobj, lcls, n_pos, per-level objectness mean..., ignored rows]."""
+        if self.autobalance:
+            obji = out[5:5 + self.nl].tolist()
+            self.balance = [b * 0.9999 + 0.0001 / o for b, o in zip(self.balance, obji)]
+            self.balance = [x / self.balance[self.ssi] for x in self.balance]
 
     def build_targets(self, p, targets):
         shapes = [(x.shape[2], x.shape[3]) for x in p]

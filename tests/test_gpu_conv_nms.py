@@ -175,3 +175,26 @@ def test_conv_nms_stage_overflow_with_mixed_ballot_counts(seed):
     want = non_max_suppression(dec, **kw)
     same(conv_nms(convs, 3, anchors, stride, **kw), want)
     assert all(int(w.shape[0]) > 2000 for w in want)
+
+
+def test_apriori_labels_on_the_fused_entries():
+    """labels= (general.py:678-684, val.py:203 with save_hybrid) on detect_nms / conv_nms / Detect.detections: the rows
+    non_max_suppression(decoded, labels=...) returns, which other tests tie to the reference's fixture."""
+    from object_detection_amd.general import conv_nms, detect_nms, non_max_suppression
+    from object_detection_amd.yolo import head_maps_decode
+    bs, nc = 3, 7
+    convs = _head(9, bs, 96, nc)
+    anchors, stride = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    rs = np.random.RandomState(4)
+    labels = [torch.from_numpy(np.concatenate([rs.randint(0, nc, (k, 1)), rs.uniform(10, 80, (k, 2)), rs.uniform(5, 30, (k, 2))], 1)
+                               .astype(np.float32)).cuda() for k in (4, 0, 2)]
+    dec, maps = head_maps_decode(convs, 3, anchors, stride)
+    for kw in (dict(conf_thres=0.05), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)):
+        want = non_max_suppression(dec, labels=labels, **kw)
+        ref = onms.non_max_suppression(dec.cpu().clone(), labels=[l.cpu() for l in labels], **kw)
+        same(want, [r.cuda() for r in ref])
+        assert any(bool((w[:, 4] == 1.0).any()) for w in want)             # a label row made it into the result
+        same(conv_nms(convs, 3, anchors, stride, labels=labels, **kw), want)
+        same(detect_nms(maps, anchors, stride, labels=labels, **kw), want)
+        # no labels for any image: the fused path
+        same(conv_nms(convs, 3, anchors, stride, labels=[l[:0] for l in labels], **kw), non_max_suppression(dec, **kw))

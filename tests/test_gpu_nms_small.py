@@ -68,7 +68,7 @@ def test_small_path_is_chosen_on_the_second_call_and_agrees():
     d = T(pred).cuda()
     G._SMALL_HINT.clear()
     rows, _, _ = G.nms_launch(d, **kw)
-    assert rows._dh_attempt[1] == G.K_SELECT                      # nothing known yet: the general first attempt
+    assert rows._dh_attempt[1] == G.K_CHAIN                       # nothing known yet: the general first attempt
     same_lists(G.non_max_suppression(d, **kw), want)
     rows, _, _ = G.nms_launch(d, **kw)
     assert rows._dh_attempt[1] == G.K_SMALL                       # a few dozen candidates per image last time
@@ -79,7 +79,7 @@ def test_small_path_is_chosen_on_the_second_call_and_agrees():
     same_lists(G.non_max_suppression(d, **kw2), want2)
     same_lists(G.non_max_suppression(d, **kw2), want2)
     rows, _, _ = G.nms_launch(d, **kw2)
-    assert rows._dh_attempt[1] == G.K_SELECT
+    assert rows._dh_attempt[1] == G.K_CHAIN
 
 
 def test_small_path_wrong_guess_falls_back():
@@ -95,7 +95,7 @@ def test_small_path_wrong_guess_falls_back():
     assert rows._dh_attempt[1] == G.K_SMALL
     same_lists(G.non_max_suppression(T(dense).cuda(), **kw), onms.non_max_suppression(T(dense).clone(), **kw))
     rows, _, _ = G.nms_launch(T(dense).cuda(), **kw)
-    assert rows._dh_attempt[1] == G.K_SELECT                      # and the guess has been corrected
+    assert rows._dh_attempt[1] == G.K_CHAIN                       # and the guess has been corrected
 
 
 def test_small_path_fused_raw_and_half():

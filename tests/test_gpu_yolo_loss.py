@@ -236,3 +236,22 @@ def test_forward_backward_in_two_halves_matches_the_fused_call():
             close(a, b, rtol=1e-6)
     with pytest.raises(RuntimeError):
         crit.forward_backward([x.clone() for x in levels], targets, positives=st)
+
+
+def test_forward_backward_autobalance_golden(golden):
+    """autobalance=True (loss.py:157-161) through the autograd-free entry: the reference's values call after call (the
+    balance weights move between calls) and its final balance."""
+    g = golden("compute_loss")
+    tag = "autobal"
+    img, bs, nc, autobal, calls = (int(v) for v in g[f"{tag}_meta"])
+    assert autobal and calls > 1
+    hyp = dict(zip(HYP_KEYS, (float(v) for v in g[f"{tag}_hyp"])))
+    crit = make_loss(T(g["anchors"]), nc, hyp, True)
+    for c in range(calls):
+        p = [T(g[f"{tag}_p{l}"]).cuda() for l in range(3)]
+        loss, items, grads = crit.forward_backward(p, T(g[f"{tag}_targets"]).reshape(-1, 6).cuda())
+        close(loss, g[f"{tag}_call{c}_loss"])
+        close(items, g[f"{tag}_call{c}_items"])
+        for l in range(3):
+            close(grads[l], g[f"{tag}_call{c}_grad{l}"])
+    close(np.array(crit.balance), g[f"{tag}_balance"])

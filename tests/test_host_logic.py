@@ -50,3 +50,26 @@ def test_bench_refuses_more_ranks_than_devices():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_nms_attempt_order():
+    """small -> one workgroup per image on the selected prefix -> (separate launches on that prefix) -> full sort."""
+    from object_detection_amd import general as G
+
+    class Rows:
+        pass
+    r = Rows()
+    r._dh_attempt = ("k", G.K_SMALL)
+    assert G._next_attempt(r, -1) == G.K_CHAIN
+    r._dh_attempt = ("k", G.K_CHAIN)
+    assert G._next_attempt(r, -2) == G.K_SELECT and G._next_attempt(r, -1) == 0
+    r._dh_attempt = ("k", G.K_SELECT)
+    assert G._next_attempt(r, -1) == 0 and G._next_attempt(r, -2) == 0
+    # flags: 1 = the prefix did not yield max_det rows (full sort next), 2 = image left to the separate launches
+    bs = 3
+    host = [0, 0] * bs + [10, 10, 10] + [0, 2, 0]
+    assert G.nms_views(r, host, 100) == (None, -2)
+    host = [0, 0] * bs + [10, 10, 10] + [1, 2, 0]
+    assert G.nms_views(r, host, 100) == (None, -1)
+    host = [0, 0] * bs + [10, 500, 10] + [0, 0, 0]
+    assert G.nms_views(r, host, 100) == (None, 500)
