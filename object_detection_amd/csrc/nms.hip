@@ -1057,24 +1057,41 @@ struct box_t {
 
 // suppress iff inter/(area_a + area_b - inter) > thr, evaluated exactly as the fp32 reference does;
 // `thr` is the largest float <= the double threshold, which makes the fp32 ">" equal to the
-// reference's comparison in double.  inter == 0 can never exceed a threshold >= 0, so the division
-// is only evaluated for overlapping pairs -- and of those only for the ones a reciprocal cannot decide: inter * rcp(union)
-// is within 3e-7 (relative) of the quotient, so a value more than 1e-6 above or below thr settles the comparison of the
-// correctly rounded quotient as well; the IEEE division (ten instructions) runs for what lies in between, and whenever the
-// operands leave the range where that bound holds.
-__device__ __forceinline__ bool suppresses(const box_t a, float area_a, const box_t b, float area_b, float thr)
+// reference's comparison in double.  inter == 0 can never exceed a threshold >= 0, so only overlapping pairs count -- and
+// of those the IEEE division (ten instructions) is evaluated only for the ones a reciprocal cannot decide: inter *
+// rcp(union) is within 3e-7 (relative) of the quotient, so a value more than 1e-6 above or below thr settles the
+// comparison of the correctly rounded quotient as well.  What lies in between, and pairs whose operands leave the
+// range where that bound holds, take the division.
+struct iou_thr {
+    float thr, hi, lo;      // hi / lo: the reciprocal's verdict is final above / below these (+-inf: never final)
+};
+
+__device__ __forceinline__ iou_thr make_iou_thr(float thr)
+{
+    iou_thr t;
+    t.thr = thr;
+    const bool usable = thr > 1e-30f;
+    t.hi = usable ? thr * 1.000001f : INFINITY;
+    t.lo = usable ? thr * 0.999999f : -INFINITY;
+    return t;
+}
+
+// Lanes (with `consider` set) whose box b is suppressed by box a.  Box a is the same in every lane (one kept box against
+// a wave of candidates): straight-line code, the division in a branch that the whole wave skips unless some lane needs it.
+__device__ __forceinline__ u64 suppressed_lanes(const box_t a, float area_a, const box_t b, float area_b, const iou_thr t, bool consider)
 {
     const float w = fmaxf(fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1), 0.0f);
     const float h = fmaxf(fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1), 0.0f);
     const float inter = w * h;
-    if (!(inter > 0.0f)) return false;
     const float uni = area_a + area_b - inter;
-    if (uni > 1e-30f && uni < 1e30f && inter < 1e30f && thr > 1e-30f) {
-        const float q = inter * __builtin_amdgcn_rcpf(uni);
-        if (q > thr * 1.000001f) return true;
-        if (q < thr * 0.999999f) return false;
-    }
-    return __fdiv_rn(inter, uni) > thr;
+    const float q = inter * __builtin_amdgcn_rcpf(uni);
+    const bool pos = consider & (inter > 0.0f);
+    const bool normal = (uni > 1e-30f) & (uni < 1e30f) & (inter < 1e30f);
+    const bool yes = pos & normal & (q > t.hi);
+    const bool no = !pos | (normal & (q < t.lo));
+    u64 m = __ballot(yes);
+    if (__ballot(!yes & !no) != 0) m |= __ballot(!yes & !no & (__fdiv_rn(inter, uni) > t.thr));      // wave-uniform, rare
+    return m;
 }
 
 // value of `v` in lane `src` (wave-uniform src): a VALU read into a scalar register, no LDS round trip
@@ -1128,6 +1145,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
     __shared__ int s_kept;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float off_scale = (agnostic || max_wh < 0.0f) ? 0.0f : max_wh;
+    const iou_thr TH = make_iou_thr(thr);
     int kept = 0;
 
     for (int base = s; base < e && kept < max_det; base += 64) {
@@ -1143,16 +1161,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
         }
         const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
         // phase 1: against everything kept so far, kept list split across the waves
-        bool sup = false;
+        u64 supm = 0;
         for (int k = wave; k < kept; k += WAVES) {
             float4 kb;
             float ka;
             if (k < KEPT_LDS) { kb = kbox[k]; ka = karea[k]; }
             else { kb = spill[k]; ka = (kb.z - kb.x) * (kb.w - kb.y); }
             const box_t kbb = {kb.x, kb.y, kb.z, kb.w};
-            sup = sup || suppresses(kbb, ka, bx, area, thr);
+            supm |= suppressed_lanes(kbb, ka, bx, area, TH, true);
         }
-        const u64 sm = __ballot(sup);
+        const u64 sm = supm;
         if (lane == 0) sup_mask[wave] = sm;
         if (wave == 0) { cbox[lane] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2); carea[lane] = area; }
         __syncthreads();
@@ -1163,8 +1181,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_nms_greedy(const float* __restri
             const int i = wave * (64 / WAVES) + q;
             const float4 bi4 = cbox[i];
             const box_t bi = {bi4.x, bi4.y, bi4.z, bi4.w};
-            const bool hit = (lane > i) && suppresses(bi, carea[i], bx, area, thr);
-            const u64 hm = __ballot(hit);
+            const u64 hm = suppressed_lanes(bi, carea[i], bx, area, TH, lane > i);
             if (lane == 0) cmask[i] = hm;
         }
         __syncthreads();
@@ -1330,6 +1347,7 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
     }
     __syncthreads();
     // greedy NMS in score order, 64 candidates at a time (the scheme of k_nms_greedy, whole-image mode)
+    const iou_thr TH = make_iou_thr(thr);
     int kept = 0;
     for (int base = 0; base < n && kept < max_det; base += 64) {
         const int p = base + lane;
@@ -1341,13 +1359,13 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
             bx.x1 = v.x + c; bx.y1 = v.y + c; bx.x2 = v.z + c; bx.y2 = v.w + c;          // general.py:721
         }
         const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
-        bool sup = false;
+        u64 supm = 0;
         for (int k = wave; k < kept; k += 16) {
             const float4 kb = kbox[k];
             const box_t kbb = {kb.x, kb.y, kb.z, kb.w};
-            sup = sup || suppresses(kbb, karea[k], bx, area, thr);
+            supm |= suppressed_lanes(kbb, karea[k], bx, area, TH, true);
         }
-        const u64 sm = __ballot(sup);
+        const u64 sm = supm;
         if (lane == 0) sup_mask[wave] = sm;
         if (wave == 0) { cbox[lane] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2); carea[lane] = area; }
         __syncthreads();
@@ -1356,8 +1374,7 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
             const int i = wave * 4 + q;
             const float4 bi4 = cbox[i];
             const box_t bi = {bi4.x, bi4.y, bi4.z, bi4.w};
-            const bool hit = (lane > i) && suppresses(bi, carea[i], bx, area, thr);
-            const u64 hm = __ballot(hit);
+            const u64 hm = suppressed_lanes(bi, carea[i], bx, area, TH, lane > i);
             if (lane == 0) cmask[i] = hm;
         }
         __syncthreads();
@@ -1562,6 +1579,7 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
         }
     }
     const bool truncated = Tn < n_lim;
+    const iou_thr TH = make_iou_thr(thr);
     if (ns > 0) {
         const uint32_t npad = pow2_ceil((uint32_t)(ns < 2 ? 2 : ns));
         for (uint32_t i = ns + threadIdx.x; i < npad; i += 1024) s_key[SIDX(i)] = KEY_SENTINEL;
@@ -1633,13 +1651,13 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
                         bx.x1 = v.x + off; bx.y1 = v.y + off; bx.x2 = v.z + off; bx.y2 = v.w + off;     // general.py:721
                     }
                     const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
-                    bool sup = false;
+                    u64 supm = 0;
                     for (int k = wave; k < kept; k += 16) {
                         const float4 kb = kbox[k];
                         const box_t kbb = {kb.x, kb.y, kb.z, kb.w};
-                        sup = sup || suppresses(kbb, karea[k], bx, area, thr);
+                        supm |= suppressed_lanes(kbb, karea[k], bx, area, TH, true);
                     }
-                    const u64 sm = __ballot(sup);
+                    const u64 sm = supm;
                     if (lane == 0) sup_mask[wave] = sm;
                     if (wave == 0) { cbox[lane] = make_float4(bx.x1, bx.y1, bx.x2, bx.y2); carea[lane] = area; }
                     __syncthreads();
@@ -1648,8 +1666,7 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
                         const int i = wave * 4 + t;
                         const float4 bi4 = cbox[i];
                         const box_t bi = {bi4.x, bi4.y, bi4.z, bi4.w};
-                        const bool hit = (lane > i) && suppresses(bi, carea[i], bx, area, thr);
-                        const u64 hm = __ballot(hit);
+                        const u64 hm = suppressed_lanes(bi, carea[i], bx, area, TH, lane > i);
                         if (lane == 0) cmask[i] = hm;
                     }
                     __syncthreads();
@@ -1702,7 +1719,7 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
                         bx.x1 = v.x + off; bx.y1 = v.y + off; bx.x2 = v.z + off; bx.y2 = v.w + off;     // general.py:721
                     }
                     const float area = (bx.x2 - bx.x1) * (bx.y2 - bx.y1);
-                    bool sup = false;
+                    u64 supm = 0;
 #pragma unroll
                     for (int pj = 0; pj < j; ++pj) {
                         u64 km = keptm[pj];
@@ -1711,10 +1728,10 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
                             km &= km - 1;
                             const float4 v = s_box[start + 64 * pj + i];
                             const box_t kb = {v.x + off, v.y + off, v.z + off, v.w + off};
-                            sup = sup || suppresses(kb, (kb.x2 - kb.x1) * (kb.y2 - kb.y1), bx, area, thr);
+                            supm |= suppressed_lanes(kb, (kb.x2 - kb.x1) * (kb.y2 - kb.y1), bx, area, TH, true);
                         }
                     }
-                    u64 todo = __ballot(valid && !sup);
+                    u64 todo = __ballot(valid) & ~supm;
                     u64 kept_mask = 0;
                     int room = max_det - kept;
                     while (todo && room > 0) {
@@ -1722,8 +1739,7 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
                         kept_mask |= 1ull << i;
                         const box_t bi = {lane_value(bx.x1, i), lane_value(bx.y1, i), lane_value(bx.x2, i), lane_value(bx.y2, i)};
                         const float ai = lane_value(area, i);
-                        const bool hit = (lane > i) && suppresses(bi, ai, bx, area, thr);
-                        todo &= ~(__ballot(hit) | (1ull << i));
+                        todo &= ~(suppressed_lanes(bi, ai, bx, area, TH, lane > i) | (1ull << i));
                         --room;
                     }
                     keptm[j] = kept_mask;
