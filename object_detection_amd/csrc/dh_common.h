@@ -17,6 +17,20 @@ typedef float dh_f4 __attribute__((ext_vector_type(4)));   // native 16-byte vec
 static inline int dh_launch_status() { return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH; }
 static inline bool dh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Compute units of the current device (256 on MI355X); asked once per device, 0 if the runtime will not say.
+static inline int dh_cu_count()
+{
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // Every fill of the library goes through this kernel, not through hipMemsetAsync.  A memset captured into a HIP graph is a
 // memset node, and on this runtime (ROCm 7.2) memset nodes are not reliable once several are replayed in turn: a captured
 // 12-byte fill with 0 that follows a 4-byte one wrote 0x0C bytes on every second replay (tools/graph_memset_probe.py).  The

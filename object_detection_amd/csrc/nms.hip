@@ -587,119 +587,244 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
 // thresholds) the whole tensor is streamed once with coalesced 16-byte loads -- at several times the rate of fetching
 // candidate rows one by one -- and every element with a class channel is tested where it lands.  The key set is the
 // same as k_nms_prefilter<true>'s; only the emission order differs, and the sort that follows does not depend on it.
-#define STREAM_UNROLL 2
-#define STREAM_TILES 16      // consecutive tiles per workgroup: candidates are gathered in LDS across them, one atomic per flush
+// The kernel is bound by instruction issue, not by memory, so the work per 16-byte vector is kept short:
+//   * a vector's four elements lie in one row, or run over into the box channels of the next one, which are never class
+//     scores: one row index and one objectness value serve the whole vector;
+//   * the streaming loop only asks whether any element of the vector could pass -- the largest of the four against the
+//     threshold, with straight-line code -- and sets the few vectors that could (a few in a hundred) aside in a queue the
+//     wave keeps in LDS; vectors holding box channels of a candidate row are set aside more often than needed;
+//   * the wave tests what it has set aside 64 vectors at a time, all lanes busy: exact arithmetic per element, class
+//     filter, keys.  The divergent code of the loop is the dozen instructions that append to the queue;
+//   * keys go to one LDS stage per workgroup and reach the image's key list with one global atomic per workgroup.  That
+//     atomic and the copy behind it are two round trips through a memory system whose queues the streaming loads keep full
+//     (several microseconds each), with the workgroup idle meanwhile: so the grid is sized to what the chip holds at once,
+//     and every workgroup streams many tiles and pays the two round trips once, at the very end.
+#define STREAM_U 4           // vectors per lane and tile: their loads are all issued before the first use
+#define STREAM_TILE (256 * STREAM_U)   // vectors per tile
+#define STREAM_MIN_TILES 8   // a workgroup streams at least this many tiles (if its image has them)
+#define STREAM_WG_PER_CU 4   // workgroups a compute unit holds (registers: 4 waves per SIMD)
+#define STREAM_ROUNDS 2       // the grid is this many times what the chip holds at once
+#define STREAM_QUEUE 256     // vectors a wave can set aside; tested whenever 64 or more are waiting
+#define STREAM_STAGE 1984    // keys a workgroup gathers in LDS (with the queues: just under 40 KB, four workgroups per
+                             // compute unit); further ones go out wave by wave
+#define STREAM_SEG_SHIFT 29  // a queued vector's index (< 2^29: an image's segment has < 2^31 elements) and, above it, its segment
 
 struct stream_seg {
     const float* src;      // (bs, elems): one level's raw map (fp32 or fp16 elements), or the whole decoded tensor
     uint32_t elems;        // elements per image
     uint32_t row_first;    // first row (anchor) of this segment inside an image
-    uint32_t blocks;
+    uint32_t tiles;        // ceil(elems / 4 / STREAM_TILE)
 };
 
 struct stream_params {
     stream_seg seg[DH_MAX_LEVELS];
     int nseg;
+    uint32_t tiles;            // per image, all segments
     dh_fastdiv no;
 };
 
+// Which of a vector's four elements are candidates, bit k for element k, and their scores: channel c0 + k of a row whose
+// objectness o is above the threshold.
+template <bool RAW>
+__device__ __forceinline__ uint32_t stream_exact(const dh_f4 x, float o, uint32_t c0, uint32_t no, float conf,
+                                                 const unsigned char* __restrict__ class_keep, float sc[4])
+{
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t c = c0 + k - 5u;                              // class, if the channel is in [5, no)
+        sc[k] = (RAW ? dh_sigmoid(xs[k]) : xs[k]) * o;               // yolo.py:62, general.py:691
+        bool ok = c < no - 5u && sc[k] > conf;                       // general.py:698
+        if (class_keep != nullptr && ok) ok = class_keep[c] != 0;    // general.py:705-706
+        bits |= ok ? 1u << k : 0u;
+    }
+    return bits;
+}
+
+// One lane's vector straight to the image's key list, for the rare lane that finds its wave's queue full.
+template <bool RAW>
+__device__ __attribute__((noinline)) void stream_direct(const dh_f4 x, float o, uint32_t v, uint32_t c0, const dh_fastdiv no,
+                                                        float conf, const unsigned char* __restrict__ class_keep,
+                                                        uint32_t row_first, int nc, int* __restrict__ count, int cap,
+                                                        u64* __restrict__ out)
+{
+    float sc[4];
+    const uint32_t row = dh_div(v * 4, no);
+    const uint32_t bits = stream_exact<RAW>(x, o, c0, no.d, conf, class_keep, sc);
+    if (!bits) return;
+    int at = atomicAdd(count, __popc(bits));
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (bits >> k & 1) {
+            if ((uint32_t)at < (uint32_t)cap) out[at] = ((u64)score_key(sc[k]) << 32) | (uint32_t)((row_first + row) * nc + (c0 + k - 5));
+            ++at;
+        }
+}
+
 template <bool RAW, typename T = float>
-__global__ void __launch_bounds__(256) k_nms_prefilter_stream(const stream_params P, const float* __restrict__ obj_plane,
+__global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(const stream_params P, const float* __restrict__ obj_plane,
                                                               int A, int nc, float conf,
                                                               const unsigned char* __restrict__ class_keep, int cap,
                                                               u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
 {
     const int b = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int l = 0;
-    uint32_t blk = blockIdx.x;
-#pragma unroll
-    for (int k = 0; k < DH_MAX_LEVELS - 1; ++k)
-        if (l == k && k + 1 < P.nseg && blk >= P.seg[k].blocks) { blk -= P.seg[k].blocks; l = k + 1; }
-    const stream_seg& G = P.seg[l];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // tiles t0, t0 + step, ...: dense and sparse stretches of the image (the coarse level's rows hold several times the
+    // candidates of the fine level's) are dealt out evenly, so that no workgroup gathers many more keys than its stage holds
+    const uint32_t t0 = blockIdx.x, step = gridDim.x, t1 = P.tiles;
+    if (t0 >= t1) return;                                            // workgroup-uniform, before any barrier
     const uint32_t no = P.no.d;
-    const uint32_t nvec = G.elems >> 2;
-    const T* __restrict__ src = reinterpret_cast<const T*>(G.src) + (size_t)b * G.elems;
-    const float* __restrict__ plane = obj_plane ? obj_plane + (size_t)b * A + G.row_first : nullptr;
     u64* __restrict__ out = keys + (size_t)b * cap_pad;
-    __shared__ u64 stage[4][STAGE_KEYS];
-    int pending = 0;
-#pragma unroll 1
-    for (int tile = 0; tile < STREAM_TILES; ++tile) {
-    const uint32_t v0 = (blk * STREAM_TILES + tile) * (256 * STREAM_UNROLL) + threadIdx.x;
-    if (v0 - threadIdx.x >= nvec) break;
-    dh_f4 x[STREAM_UNROLL];
-    float o0[STREAM_UNROLL], o1[STREAM_UNROLL];
-    uint32_t row[STREAM_UNROLL], c0[STREAM_UNROLL];
-    // every load of the tile is issued before the first use: the data vectors and the objectness of the (at most two)
-    // rows each vector belongs to
+    __shared__ dh_f4 qx[4][STREAM_QUEUE];          // the vectors set aside, per wave,
+    __shared__ uint2 qm[4][STREAM_QUEUE];          // with their row's objectness and their index
+    __shared__ u64 stage[STREAM_STAGE];
+    __shared__ uint32_t s_row_first[DH_MAX_LEVELS];
+    __shared__ int q_n[4], s_n, s_valid, s_base;
+    if (threadIdx.x < 4) q_n[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        s_n = 0; s_valid = STREAM_STAGE;
 #pragma unroll
-    for (int u = 0; u < STREAM_UNROLL; ++u) {
-        const uint32_t v = v0 + u * 256;
-        o0[u] = 0.0f; o1[u] = 0.0f; row[u] = 0; c0[u] = 0;
-        if (v < nvec) {
-            x[u] = ld4_nt(src, v);
-            const uint32_t e = v * 4;
-            row[u] = dh_div(e, P.no);
-            c0[u] = e - row[u] * no;
-            const bool two = c0[u] + 3 >= no;
-            if (RAW || !plane) {
-                o0[u] = ldf(src + (size_t)row[u] * no + 4);
-                if (two) o1[u] = ldf(src + (size_t)(row[u] + 1) * no + 4);
-            } else {
-                o0[u] = plane[row[u]];
-                if (two) o1[u] = plane[row[u] + 1];
-            }
-        }
+        for (int k = 0; k < DH_MAX_LEVELS; ++k) s_row_first[k] = k < P.nseg ? P.seg[k].row_first : 0;
     }
-#pragma unroll
-    for (int u = 0; u < STREAM_UNROLL; ++u) {
-        const uint32_t v = v0 + u * 256;
-        const bool live = v < nvec;
-        const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-        const float oa = RAW ? dh_sigmoid(o0[u]) : o0[u], ob = RAW ? dh_sigmoid(o1[u]) : o1[u];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            uint32_t ch = c0[u] + k, r = row[u];
-            float o = oa;
-            if (ch >= no) { ch -= no; r += 1; o = ob; }
-            const int c = (int)ch - 5;
-            const float val = RAW ? dh_sigmoid(xs[k]) : xs[k];                                  // yolo.py:62
-            const float sc = val * o;                                                           // general.py:691
-            bool pass = live && c >= 0 && (o > conf) && (sc > conf);                            // general.py:656,698
-            if (class_keep != nullptr && pass) pass = class_keep[c] != 0;                       // general.py:705-706
-            const u64 pm = __ballot(pass);
-            if (pm) {
-                if (pass) stage[wave][pending + __popcll(pm & lanemask_lt())] =
-                    ((u64)score_key(sc) << 32) | (uint32_t)((G.row_first + r) * nc + c);
-                pending += __popcll(pm);
-            }
-        }
-        if (pending > STAGE_KEYS - 4 * 64) {            // one atomic per > 256 keys; the next vector adds at most 256
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&counts[b], pending);
-            base = __shfl(base, 0, 64);
-            for (int i = lane; i < pending; i += 64)
-                if (base + i < cap) out[base + i] = stage[wave][i];
-            pending = 0;
-        }
-    }
-    }
-    // what the four waves still hold goes out with one atomic (every wave of the workgroup leaves the tile loop, whose
-    // trip count does not depend on the wave, and meets here)
-    __shared__ int s_cnt[4], s_base;
-    if (lane == 0) s_cnt[wave] = pending;
     __syncthreads();
-    int before = 0, total = 0;
+    const float conf_pre = RAW ? conf * 0.9999f : conf;              // raw maps: the largest element goes through the sigmoid
+                                                                     // alone; the margin covers any non-monotonic rounding
+    // decoded tensor (one segment): a row's objectness is in the compact plane the decode left, or in channel 4 of the row
+    const float* __restrict__ plane = (!RAW && obj_plane) ? obj_plane + (size_t)b * A + P.seg[0].row_first : nullptr;
+    const float* __restrict__ obj = plane ? plane : P.seg[0].src + (size_t)b * P.seg[0].elems + 4;
+    const uint32_t obj_stride = plane ? 1u : no;
+    // tests the n vectors the wave has set aside (all 64 lanes call this together)
+    auto drain = [&](int n) {
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const bool live = i < n;
+            const dh_f4 xv = qx[w][live ? i : 0];
+            const uint2 m = qm[w][live ? i : 0];
+            const float o = __uint_as_float(m.x);
+            const uint32_t e = (m.y & ((1u << STREAM_SEG_SHIFT) - 1)) * 4, row = dh_div(e, P.no), c0 = e - row * no;
+            const uint32_t row_g = s_row_first[m.y >> STREAM_SEG_SHIFT] + row;
+            float sc[4];
+            uint32_t bits = stream_exact<RAW>(xv, o, c0, no, conf, class_keep, sc);
+            if (!live) bits = 0;
+            const int cnt = __popc(bits);
+            int incl = cnt;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const int c = s_cnt[w]; if (w < wave) before += c; total += c; }
-    if (total) {
-        if (threadIdx.x == 0) s_base = atomicAdd(&counts[b], total);
-        __syncthreads();
-        const int base = s_base + before;
-        for (int i = lane; i < pending; i += 64)
-            if (base + i < cap) out[base + i] = stage[wave][i];
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_up(incl, d);
+                if (lane >= d) incl += t;
+            }
+            const int total = __shfl(incl, 63);
+            if (total == 0) continue;                                // wave-uniform
+            int first = 0, direct = 0;
+            if (lane == 0) {
+                first = atomicAdd(&s_n, total);
+                direct = first + total > STREAM_STAGE;               // no room in the stage: straight to the image's list
+                if (direct) {                                        // (s_n only grows, see conv_emit)
+                    atomicMin(&s_valid, first);
+                    first = atomicAdd(&counts[b], total);
+                }
+            }
+            first = __shfl(first, 0);
+            direct = __shfl(direct, 0);
+            int at = first + incl - cnt;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (bits >> k & 1) {
+                    const u64 key = ((u64)score_key(sc[k]) << 32) | (uint32_t)(row_g * nc + (c0 + k - 5));
+                    if (!direct) stage[at] = key;
+                    else if ((uint32_t)at < (uint32_t)cap) out[at] = key;
+                    ++at;
+                }
+        }
+    };
+    // one tile's loads, all issued before anything waits for them; vi = vector index in its segment | segment << 29
+    auto issue = [&](uint32_t t, dh_f4 (&x)[STREAM_U], float (&oraw)[STREAM_U], uint32_t (&c0)[STREAM_U], uint32_t (&vi)[STREAM_U]) {
+        const bool tile_live = t < t1;                               // a tile past the end is asked for, and ignored
+        uint32_t tt = tile_live ? t : t0;
+        int l = 0;
+#pragma unroll
+        for (int k = 0; k < DH_MAX_LEVELS - 1; ++k)
+            if (l == k && k + 1 < P.nseg && tt >= P.seg[k].tiles) { tt -= P.seg[k].tiles; l = k + 1; }
+        const stream_seg& G = P.seg[l];
+        const uint32_t nvec = G.elems >> 2;
+        const T* __restrict__ src = reinterpret_cast<const T*>(G.src) + (size_t)b * G.elems;
+        const uint32_t v0 = tt * STREAM_TILE + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < STREAM_U; ++u) {
+            const uint32_t v = v0 + u * 256;
+            const bool live = tile_live && v < nvec;
+            const uint32_t vv = live ? v : 0;
+            vi[u] = vv | ((uint32_t)l << STREAM_SEG_SHIFT);
+            const uint32_t e = vv * 4, row = dh_div(e, P.no);
+            c0[u] = live ? e - row * no : no;                       // c0 = no: a dead vector has no class channel
+            x[u] = ld4_nt(src, vv);
+            if constexpr (RAW) oraw[u] = ldf(src + (size_t)row * no + 4);
+            else oraw[u] = obj[(size_t)row * obj_stride];
+        }
+    };
+    // one tile's vectors: set aside those that may hold a candidate
+    auto sift = [&](const dh_f4 (&x)[STREAM_U], const float (&oraw)[STREAM_U], const uint32_t (&c0)[STREAM_U],
+                    const uint32_t (&vi)[STREAM_U]) {
+#pragma unroll
+        for (int u = 0; u < STREAM_U; ++u) {
+            const float o = RAW ? dh_sigmoid(oraw[u]) : oraw[u];
+            const bool has_cls = c0[u] - 2u < no - 2u;              // some channel c0 .. c0+3 lies in [5, no)
+            float mx;
+            if (RAW) {
+                mx = dh_sigmoid(fmaxf(fmaxf(x[u].x, x[u].y), fmaxf(x[u].z, x[u].w)));
+            } else {                                                // decoded box channels are pixels, far above any score:
+                const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};       // only class channels enter the maximum
+                mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) mx = fmaxf(mx, c0[u] + k - 5u < no - 5u ? xs[k] : -INFINITY);
+            }
+            const bool maybe = mx * o > conf_pre;
+            if ((o > conf) & has_cls & maybe) {                     // general.py:656,675 and a bound on general.py:691,698
+                const int slot = atomicAdd(&q_n[w], 1);
+                if (slot < STREAM_QUEUE) {
+                    qx[w][slot] = x[u];
+                    qm[w][slot] = make_uint2(__float_as_uint(o), vi[u]);
+                } else {                                            // queue full: a tile of nothing but candidates on top
+                    stream_direct<RAW>(x[u], o, vi[u] & ((1u << STREAM_SEG_SHIFT) - 1), c0[u], P.no, conf, class_keep,
+                                       s_row_first[vi[u] >> STREAM_SEG_SHIFT], nc, &counts[b], cap, out);
+                }                                                   // of what was waiting
+            }
+        }
+        // the wave's own queue: LDS operations of one wave complete in order, so every lane reads the same count
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int n = __builtin_amdgcn_readfirstlane(q_n[w]);
+        if (n >= 64) {                                              // enough to keep every lane busy
+            drain(min(n, STREAM_QUEUE));
+            if (lane == 0) q_n[w] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    };
+    // the workgroup's tiles, the next one's loads in flight while this one is looked at (two register sets, swapped by hand).
+    // The loads of a tile are issued whether it exists or not: a branch around them would make the loop wait for the
+    // newest loads in flight, not the oldest, where the two paths meet.
+    dh_f4 xa[STREAM_U], xb[STREAM_U];
+    float oa[STREAM_U], ob[STREAM_U];
+    uint32_t ca[STREAM_U], cb[STREAM_U], va[STREAM_U], vb[STREAM_U];
+    issue(t0, xa, oa, ca, va);
+#pragma unroll 1
+    for (uint32_t t = t0; t < t1; t += 2 * step) {
+        issue(t + step, xb, ob, cb, vb);
+        sift(xa, oa, ca, va);
+        issue(t + 2 * step, xa, oa, ca, va);
+        sift(xb, ob, cb, vb);
     }
+    {
+        const int n = __builtin_amdgcn_readfirstlane(q_n[w]);
+        if (n > 0) drain(min(n, STREAM_QUEUE));
+    }
+    __syncthreads();
+    const int n = min(s_n, s_valid);                                // the staged keys
+    if (n == 0) return;                                             // workgroup-uniform
+    if (threadIdx.x == 0) s_base = atomicAdd(&counts[b], n);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256)
+        if ((uint32_t)(s_base + i) < (uint32_t)cap) out[s_base + i] = stage[i];
 }
 
 // ------------------------------------------------------------------------------------------ 2/4 sort
@@ -2080,9 +2205,8 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
 
     int* cursor = (int*)(ws + L.off_cursor);
     if (dh_fill_async(ws, 0, L.zero_bytes, st) != DH_OK) return DH_ERR_LAUNCH;   // every counter's initial state is 0
-    // Multi-label at a validation-style threshold straight from the raw maps: most rows are candidates and there is no
-    // compact objectness plane to scan, so the maps are streamed once instead of being visited row by row (measured
-    // 163 against 278 us at bs 64).  With a decoded tensor and its plane the row-by-row kernel stays ahead.
+    // Multi-label at a validation-style threshold: most rows are candidates, so the tensor (decoded, or the raw maps) is
+    // streamed once instead of being visited candidate row by candidate row.
     bool streamed = false;
     if (S.conv_na) {          // convolution layout: its own candidate search, everything after it is shared
         conv_blocks CB;
@@ -2097,7 +2221,7 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
 #undef DH_CONV
         streamed = true;
     }
-    if (!streamed && raw && multi_label && conf_thres < 0.05 && nc + 5 >= 7) {
+    if (!streamed && multi_label && conf_thres < 0.05 && nc + 5 >= 7) {
         stream_params SP;
         SP.no = dh_make_fastdiv((uint32_t)(nc + 5));
         bool ok = true;
@@ -2113,11 +2237,20 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
             ok = (unsigned long long)A * (nc + 5) < (1ull << 31);
             SP.seg[0].elems = ok ? (uint32_t)A * (uint32_t)(nc + 5) : 0;
         }
+        SP.tiles = 0;
         for (int l = 0; ok && l < SP.nseg; ++l) {
             ok = (SP.seg[l].elems % 4 == 0) && (half ? (reinterpret_cast<uintptr_t>(SP.seg[l].src) & 7u) == 0 : dh_aligned16(SP.seg[l].src));
-            SP.seg[l].blocks = (SP.seg[l].elems / 4 + 256 * STREAM_UNROLL * STREAM_TILES - 1) / (256 * STREAM_UNROLL * STREAM_TILES);
-            sgx += SP.seg[l].blocks;
+            SP.seg[l].tiles = (SP.seg[l].elems / 4 + STREAM_TILE - 1) / STREAM_TILE;
+            SP.tiles += SP.seg[l].tiles;
         }
+        // as many workgroups as the chip holds at once, shared out evenly over the images; none shorter than STREAM_MIN_TILES
+        const int cus = dh_cu_count();
+        uint32_t per_image = (uint32_t)((cus > 0 ? cus : 256) * STREAM_WG_PER_CU * STREAM_ROUNDS / bs);
+        if (per_image < 1) per_image = 1;
+        const uint32_t most = (SP.tiles + STREAM_MIN_TILES - 1) / STREAM_MIN_TILES;
+        if (per_image > most) per_image = most;
+        ok = ok && SP.tiles > 0 && SP.tiles < (1u << 30);
+        sgx = per_image;
         if (ok) {
             if (raw && half) hipLaunchKernelGGL((k_nms_prefilter_stream<true, _Float16>), dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane,
                                                 A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);

@@ -251,6 +251,32 @@ def test_fused_decode_nms_equals_two_calls_and_oracle(kw):
     assert sum(t.shape[0] for t in two) > 20
 
 
+@pytest.mark.parametrize("nc", [2, 3, 20, 80])
+def test_streamed_candidate_search_with_most_pairs_passing(nc):
+    """Validation threshold, multi-label, nearly every (row, class) pair a candidate: far more keys than one workgroup
+    gathers in LDS before it writes them out; row lengths that start rows at every offset of a 16-byte vector; the decoded
+    tensor with and without its objectness plane, the raw maps in fp32 and fp16, and a class filter."""
+    from object_detection_amd.general import detect_nms, non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    from oracle import yolo as oy
+    from tests._synth import synth_head
+    rs = np.random.RandomState(400 + nc)
+    levels = synth_head(rs, 2, 64, nc)
+    for x in levels:
+        x[..., 4] = rs.normal(0.5, 1.5, x.shape[:-1])
+        x[..., 5:] = rs.normal(1.0, 1.0, x[..., 5:].shape)
+    anchors, strides = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    for kw in (dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+               dict(conf_thres=0.03, iou_thres=0.5, multi_label=True, classes=[0, nc - 1], max_det=1000)):
+        for dev in ([T(x).cuda() for x in levels], [T(x).cuda().half() for x in levels]):
+            z = detect_decode(dev, anchors, strides)
+            want = onms.non_max_suppression(z.cpu().clone(), **kw)
+            assert sum(w.shape[0] for w in want) > 20
+            same_lists(non_max_suppression(z, **kw), want)                  # objectness plane of the decode
+            same_lists(non_max_suppression(z.clone(), **kw), want)          # strided objectness column
+            same_lists(detect_nms(dev, anchors, strides, **kw), want)
+
+
 def test_nms_prefix_selection_and_its_fallback():
     """Only the best-scoring few thousand candidates go through NMS on the first attempt.  (a) plenty of distinct
     objects: the prefix yields max_det rows and is final; (b) one tight cluster: it does not, the launch says so, and
