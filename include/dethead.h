@@ -78,6 +78,16 @@ int dh_yolo_decode_f16(const void* const* level_ptrs, const int* ny, const int* 
                        const float* anchor_px, const float* strides, float* out, float* obj_plane, float* obj_logit_plane,
                        void* stream);
 
+/* Detect.forward's inference branch as a half-precision model computes it (model.half(),
+ * object_detection/yolov5/val.py:129-130; models/yolo.py:56-70 with fp16 maps and float grid / anchor_grid, yolo.py:78-80):
+ * fp16 roundings after the sigmoid, after -0.5 and after **2, fp32 for + grid, * stride and * anchor_grid, and one more
+ * rounding into the fp16 result.  inplace != 0 (yolo.py:59-61): out is (bs, A, no) fp16.  inplace == 0 (the torch.cat form,
+ * yolo.py:63-65): out is (bs, A, no) fp32, xy and wh are the fp32 values before that last rounding and the rest are the
+ * fp16 sigmoids widened, which is what the cat of float and half tensors yields.  anchor_px must be the model's anchor_grid
+ * values, (anchors.half() * stride).float().  obj_plane as in dh_yolo_decode (the fp16 objectness values as fp32). */
+int dh_yolo_decode_half(const void* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                        const float* anchor_px, const float* strides, int inplace, void* out, float* obj_plane, void* stream);
+
 /* Detect.forward from the outputs of its 1x1 convolutions onward (object_detection/yolov5/models/yolo.py:53-70):
  * conv_ptrs[l] is the convolution output of level l, (bs, na*no, ny, nx) contiguous; map_ptrs[l] receives
  * x[i].view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous(), i.e. the (bs, na, ny, nx, no) head map (yolo.py:54);
@@ -133,6 +143,20 @@ int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int
                    int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
                    double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count, int* needs_full,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* non_max_suppression on a decoded tensor in fp16, as the reference runs it behind a half-precision model
+ * (object_detection/yolov5/val.py:129-130,203): conf = obj * cls rounded to fp16 (utils/general.py:691), corners formed in
+ * fp16 (general.py:694,553-560), fp32 from the torch.cat with the float class column on (general.py:699,702).
+ * dh_nms_prepare_f16 does the fp16 part: pred_f16 (bs, A, 5+nc) fp16 -> out (bs, A, 5+nc) fp32 holding x1, y1, x2, y2,
+ * the outcome of obj > conf_thres (1 or 0) and the conf values.  image_fp32 (optional, bs bytes): images flagged there are
+ * computed in fp32 from the widened values, which is what the cat with the float label rows does to an image that has
+ * apriori labels (general.py:678-684).  dh_nms_batched_prepared is dh_nms_batched on such a tensor (arguments as there). */
+int dh_nms_prepare_f16(const void* pred_f16, int bs, int A, int nc, double conf_thres, const unsigned char* image_fp32,
+                       float* out, void* stream);
+int dh_nms_batched_prepared(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres, int multi_label,
+                            int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+                            int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* Fused inference path: the NMS of dh_nms_batched fed directly by the raw head maps of dh_yolo_decode (same level
  * description), i.e. non_max_suppression(Detect(x)[0]) of object_detection/yolov5/val.py:194,203 and detect.py:126,132

@@ -207,6 +207,101 @@ int decode_run(const float* const* level_ptrs, bool half, const int* ny, const i
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------ half-precision model
+// Behind model.half() (val.py:129-130) the head's maps, its sigmoid and the decoded tensor are fp16, while the grid and the
+// anchor grid are float tensors (yolo.py:78-80): torch rounds to fp16 after the sigmoid, after *2 (exact), after -0.5 and
+// after **2, widens for + grid, * stride and * anchor_grid, and rounds once more when the result is assigned into the fp16
+// tensor (yolo.py:59-61).  This kernel performs exactly those roundings and writes fp16.  anchor_px must be what
+// _make_grid holds on such a model: (anchors.half() * stride).float().
+namespace {
+
+__device__ __forceinline__ float dh_round_f16(float v) { return (float)(_Float16)v; }
+
+__device__ __forceinline__ float decode_box_half(const decode_level& L, uint32_t row, uint32_t c, float s)
+{
+    const uint32_t a = dh_div(row, L.plane);
+    const uint32_t cell = row - a * L.plane.d;
+    const uint32_t gy = dh_div(cell, L.nx);
+    const uint32_t gx = cell - gy * L.nx.d;
+    const float g = (float)((c & 1u) ? gy : gx);
+    const float t = s * 2.0f;                                                  // exact in fp16
+    const float xy = (dh_round_f16(t - 0.5f) + g) * L.stride;                  // yolo.py:60
+    const float wh = dh_round_f16(t * t) * L.anchor_px[2 * a + (c & 1u)];      // yolo.py:61
+    return c < 2 ? xy : wh;
+}
+
+// one thread: VEC consecutive elements of one level of one image (VEC = 4: one 8-byte load).  OUT = _Float16: the in-place
+// form (yolo.py:59-61), every value rounded into the fp16 tensor.  OUT = float: the torch.cat form (yolo.py:63-65), where
+// xy and wh stay the fp32 values they were computed as and the cat widens the fp16 rest.
+template <int VEC, typename OUT>
+__global__ void __launch_bounds__(256) k_yolo_decode_half(const decode_params P, OUT* __restrict__ out)
+{
+    const int b = blockIdx.y;
+    int l = 0;
+    uint32_t blk = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < DH_MAX_LEVELS - 1; ++k) {
+        if (l == k && k + 1 < P.nl && blk >= P.blocks[k]) { blk -= P.blocks[k]; l = k + 1; }
+    }
+    const decode_level& L = P.lvl[l];
+    const uint32_t nvec = L.elems / VEC;
+    const uint32_t no = P.no.d;
+    const uint32_t v = blk * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    const _Float16* __restrict__ src = reinterpret_cast<const _Float16*>(L.src) + (size_t)b * L.elems + (size_t)v * VEC;
+    OUT* __restrict__ dst = out + (size_t)b * P.per_image + L.first + (size_t)v * VEC;
+    _Float16 x[VEC];
+    OUT y[VEC];
+    if (VEC == 4) *reinterpret_cast<dh_h4*>(x) = __builtin_nontemporal_load(reinterpret_cast<const dh_h4*>(src));
+    else x[0] = src[0];
+    uint32_t row = dh_div(v * VEC, P.no), c = v * VEC - row * no;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        float s = dh_round_f16(dh_sigmoid((float)x[k]));                       // yolo.py:58
+        if (c < 4) s = decode_box_half(L, row, c, s);
+        y[k] = (OUT)s;                                                         // OUT = _Float16: the assignment into the fp16 tensor
+        if (c == 4 && P.obj_plane) P.obj_plane[(size_t)b * P.rows_per_image + L.row_first + row] = s;
+        if (++c == no) { c = 0; ++row; }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) dst[k] = y[k];                               // consecutive: merged into one store when aligned
+}
+
+}  // namespace
+
+extern "C" int dh_yolo_decode_half(const void* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                                   const float* anchor_px, const float* strides, int inplace, void* out, float* obj_plane,
+                                   void* stream)
+{
+    if (nl < 1 || nl > DH_MAX_LEVELS || na < 1 || na > DH_MAX_ANCHORS || no < 5 || bs < 0 || bs > 65535) return DH_ERR_ARG;
+    if (!level_ptrs || !ny || !nx || !anchor_px || !strides || (bs > 0 && !out)) return DH_ERR_ARG;
+    if (bs == 0) return DH_OK;
+    decode_params P;
+    P.nl = nl;
+    P.no = dh_make_fastdiv((uint32_t)no);
+    bool vec4 = false;
+    if (!dh_make_levels(reinterpret_cast<const float* const*>(level_ptrs), ny, nx, nl, na, no, anchor_px, strides, P.lvl, &P.per_image,
+                        &P.rows_per_image, &vec4, 7))
+        return DH_ERR_ARG;
+    for (int l = 0; l < nl; ++l)
+        if (reinterpret_cast<uintptr_t>(level_ptrs[l]) & 1u) return DH_ERR_ALIGN;
+    if (reinterpret_cast<uintptr_t>(out) & (inplace ? 1u : 3u)) return DH_ERR_ALIGN;
+    P.obj_plane = obj_plane;
+    P.logit_plane = nullptr;
+    const int vec = vec4 ? 4 : 1;
+    uint32_t gx = 0;
+    for (int l = 0; l < nl; ++l) {
+        P.blocks[l] = (P.lvl[l].elems / vec + 255) / 256;
+        gx += P.blocks[l];
+    }
+    hipStream_t st = (hipStream_t)stream;
+#define DH_DEC_HALF(V, O) hipLaunchKernelGGL((k_yolo_decode_half<V, O>), dim3(gx, bs), dim3(256), 0, st, P, (O*)out)
+    if (inplace) { if (vec4) DH_DEC_HALF(4, _Float16); else DH_DEC_HALF(1, _Float16); }
+    else { if (vec4) DH_DEC_HALF(4, float); else DH_DEC_HALF(1, float); }
+#undef DH_DEC_HALF
+    return dh_launch_status();
+}
+
 extern "C" int dh_yolo_decode(const float* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
                               int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
                               float* obj_logit_plane, void* stream)

@@ -70,7 +70,16 @@ struct nms_source {
     int nl, no;
     int conv_na;     // 0: lvl[].src are head maps (bs, na, ny, nx, no); na > 0: they are the outputs of the head's 1x1
                      // convolutions, (bs, na*no, ny, nx), where channel c of a row sits ny*nx elements after channel c - 1
+    int corners;     // pred rows hold the corners x1, y1, x2, y2 already (k_nms_prepare_f16), not centre and size
 };
+
+// channels 0..3 of a row of the decoded tensor as corners (general.py:553-560)
+__device__ __forceinline__ float4 pred_corners(const nms_source& S, const float* __restrict__ p)
+{
+    const float x = p[0], y = p[1], w = p[2], h = p[3];
+    if (S.corners) return make_float4(x, y, w, h);
+    return make_float4(x - w / 2, y - h / 2, x + w / 2, y + h / 2);
+}
 
 // The raw maps hold fp32 or fp16 elements (T = float or _Float16; decode_level::src is then a pointer in disguise).
 // fp16 values are widened to fp32 on load and everything after that is the fp32 arithmetic, so a half-precision head
@@ -1127,19 +1136,19 @@ __global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, d
         uint32_t anchor = dh_div(ord, ncd);
         const uint32_t cls = ord - anchor * ncd.d;
         if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;      // a key always names a row of the image: never address beyond it
-        float x, y, w, h;
+        float x1, y1, x2, y2;                                                           // general.py:553-560
         if (RAW) {
             const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
             const decode_level& L = S.lvl[rr.l];
-            x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
-            y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
-            w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
-            h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
+            const float x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
+            const float y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
+            const float w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
+            const float h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
+            x1 = x - w / 2; y1 = y - h / 2; x2 = x + w / 2; y2 = y + h / 2;
         } else {
-            const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
-            x = p[0]; y = p[1]; w = p[2]; h = p[3];
+            const float4 c = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
+            x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
         }
-        const float x1 = x - w / 2, y1 = y - h / 2, x2 = x + w / 2, y2 = y + h / 2;     // general.py:553-560
         float* __restrict__ d = det + ((size_t)b * m_cap + r) * 6;
         d[0] = x1; d[1] = y1; d[2] = x2; d[3] = y2;
         d[4] = key_score((uint32_t)(key >> 32));
@@ -1455,19 +1464,17 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
         uint32_t anchor = dh_div(ord, ncd);
         const uint32_t cls = ord - anchor * ncd.d;
         if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;      // a key always names a row of the image: never address beyond it
-        float x, y, w, h;
         if (RAW) {
             const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
             const decode_level& L = S.lvl[rr.l];
-            x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
-            y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
-            w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
-            h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
+            const float x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
+            const float y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
+            const float w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
+            const float h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
+            s_box[threadIdx.x] = make_float4(x - w / 2, y - h / 2, x + w / 2, y + h / 2);
         } else {
-            const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
-            x = p[0]; y = p[1]; w = p[2]; h = p[3];
+            s_box[threadIdx.x] = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
         }
-        s_box[threadIdx.x] = make_float4(x - w / 2, y - h / 2, x + w / 2, y + h / 2);
         s_off[threadIdx.x] = agnostic ? 0.0f : (float)cls * max_wh;                      // general.py:720
     }
     __syncthreads();
@@ -1720,19 +1727,19 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
             const int cls = (int)(ck >> 55);
             uint32_t anchor = (uint32_t)ck & ((1u << GRP_ANCHOR_BITS) - 1u);
             if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;
-            float x, y, w, h;
+            float x1, y1, x2, y2;
             if (RAW) {
                 const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
                 const decode_level& L = S.lvl[rr.l];
-                x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
-                y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
-                w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
-                h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
+                const float x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
+                const float y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
+                const float w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
+                const float h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
+                x1 = x - w / 2; y1 = y - h / 2; x2 = x + w / 2; y2 = y + h / 2;
             } else {
-                const float* __restrict__ p = S.pred + ((size_t)b * A + anchor) * no;
-                x = p[0]; y = p[1]; w = p[2]; h = p[3];
+                const float4 c = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
+                x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
             }
-            const float x1 = x - w / 2, y1 = y - h / 2, x2 = x + w / 2, y2 = y + h / 2;
             s_box[i] = make_float4(x1, y1, x2, y2);
             bad = bad || !(fabsf(x1) < win && fabsf(y1) < win && fabsf(x2) < win && fabsf(y2) < win);
             if (cls < nc) {
@@ -2348,7 +2355,76 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
     S.nl = 0;
     S.no = nc + 5;
     S.conv_na = 0;
+    S.corners = 0;
     return nms_run(S, false, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
+                   max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
+}
+
+// ------------------------------------------------------------------------------------------ half-precision predictions
+// A decoded tensor in fp16 is what the reference's NMS sees behind a half-precision model (val.py:129-130,185).  Its
+// arithmetic is then fp16 up to the point where the detection matrix is assembled: conf = obj * cls is rounded to fp16
+// (general.py:691), the corners are formed in fp16 (general.py:694,553-560), and torch.cat with the float class column
+// (general.py:699,702) widens both; everything after that is fp32.  An image with apriori labels is widened earlier, by
+// the cat with the float label rows (general.py:678-684), and has the fp32 arithmetic throughout.  This kernel does the
+// fp16 part and leaves an fp32 tensor the fp32 pipeline turns into exactly the reference's rows: corners in channels 0..3,
+// conf in the class channels, and in channel 4 the outcome of the objectness test (1 or 0) -- so that the pipeline's own
+// "obj > conf" keeps what passed, its "obj * cls" returns conf unchanged, and the corners are taken as they are
+// (nms_source::corners).  Thresholds are compared in fp32, as the reference's device kernels compare an fp16 tensor with
+// a Python scalar.
+__device__ __forceinline__ float round_f16(float v) { return (float)(_Float16)v; }
+
+__global__ void __launch_bounds__(256) k_nms_prepare_f16(const _Float16* __restrict__ pred, int rows_per_image, int no, float conf,
+                                                         const unsigned char* __restrict__ image_fp32, float* __restrict__ out,
+                                                         size_t rows)
+{
+    const int lane = threadIdx.x & 63;
+    for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (size_t)gridDim.x * 4) {     // one wave per row
+        const _Float16* __restrict__ p = pred + row * (size_t)no;
+        float* __restrict__ o = out + row * (size_t)no;
+        const bool wide = image_fp32 != nullptr && image_fp32[row / (size_t)rows_per_image] != 0;
+        const float obj = (float)p[4];
+        if (lane < 4) {
+            const float c = (float)p[lane & 1], sz = (float)p[2 + (lane & 1)];         // centre and size along this lane's axis
+            const float half_size = wide ? sz / 2 : round_f16(sz / 2);
+            const float v = (lane & 2) ? c + half_size : c - half_size;                 // general.py:556-559
+            o[lane] = wide ? v : round_f16(v);
+        } else if (lane == 4) {
+            o[4] = obj > conf ? 1.0f : 0.0f;                                            // general.py:656,675
+        }
+        for (int c = 5 + lane; c < no; c += 64) {
+            const float v = (float)p[c] * obj;                                          // general.py:691 (exact in fp32: 11 x 11 bits)
+            o[c] = wide ? v : round_f16(v);
+        }
+    }
+}
+
+extern "C" int dh_nms_prepare_f16(const void* pred_f16, int bs, int A, int nc, double conf_thres, const unsigned char* image_fp32,
+                                  float* out, void* stream)
+{
+    if (bs < 0 || A < 0 || nc < 1) return DH_ERR_ARG;
+    const size_t rows = (size_t)bs * (size_t)A;
+    if (rows == 0) return DH_OK;
+    if (!pred_f16 || !out) return DH_ERR_ARG;
+    size_t blocks = (rows + 3) / 4;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_nms_prepare_f16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)pred_f16, A, nc + 5,
+                       (float)conf_thres, image_fp32, out, rows);
+    return dh_launch_status();
+}
+
+extern "C" int dh_nms_batched_prepared(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres,
+                                       int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
+                                       int max_nms, double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                       int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (bs > 0 && !pred) return DH_ERR_ARG;
+    nms_source S;
+    S.pred = pred;
+    S.nl = 0;
+    S.no = nc + 5;
+    S.conv_na = 0;
+    S.corners = 1;
+    return nms_run(S, false, false, nullptr, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
                    max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
 
@@ -2472,6 +2548,7 @@ int decode_nms_run(const void* const* level_ptrs, bool half, bool conv, const in
     S.nl = nl;
     S.no = no;
     S.conv_na = conv ? na : 0;
+    S.corners = 0;
     uint32_t per_image = 0, rows = 0;
     if (!dh_make_levels(reinterpret_cast<const float* const*>(level_ptrs), ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image,
                         &rows, nullptr))

@@ -109,11 +109,12 @@ def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
     return coords
 
 
-def _with_apriori_labels(pred, labels, nc):
+def _with_apriori_labels(pred, labels, nc, corners=False):
     """general.py:678-684: label rows [cls,x,y,w,h] join an image's candidates with obj = cls score = 1.
 
     They are appended as extra prediction rows (objectness 0 rows pad shorter images and can never be
     candidates), which keeps them behind every real anchor in candidate order, as in the reference.
+    corners: `pred` holds x1, y1, x2, y2 (_prepared_from_half), so the label boxes are converted the same way.
     """
     extra = max((len(l) for l in labels), default=0)
     if extra == 0:
@@ -123,10 +124,27 @@ def _with_apriori_labels(pred, labels, nc):
     for i, l in enumerate(labels):
         if len(l):
             l = l.to(pred.device).float()
-            pad[i, :len(l), :4] = l[:, 1:5]
+            pad[i, :len(l), :4] = xywh2xyxy(l[:, 1:5]) if corners else l[:, 1:5]
             pad[i, :len(l), 4] = 1.0
             pad[i, torch.arange(len(l), device=pred.device), l[:, 0].long() + 5] = 1.0
     return torch.cat((pred, pad), 1)
+
+
+def _prepared_from_half(prediction, conf_thres, labels):
+    """The fp16 part of the reference's NMS on an fp16 prediction tensor (what a half-precision model hands it,
+    val.py:129-130,203): conf = obj * cls and the corners rounded to fp16 (general.py:691,694), returned as the fp32
+    tensor torch.cat leaves at general.py:699,702.  Images with apriori labels were widened before that, by the cat with the
+    float label rows (general.py:684), and are computed in fp32.  See dh_nms_prepare_f16."""
+    pred = prediction.contiguous()
+    bs, A, no = pred.shape
+    wide = None
+    if labels and len(labels):
+        wide = torch.tensor([1 if len(l) else 0 for l in labels], dtype=torch.uint8).to(pred.device)
+    out = torch.empty((bs, A, no), dtype=torch.float32, device=pred.device)
+    with L.device_guard(pred.device):
+        L.check(L.lib().dh_nms_prepare_f16(L.ptr(pred), bs, A, no - 5, float(conf_thres), L.ptr(wide), L.ptr(out), L.stream()),
+                "dh_nms_prepare_f16")
+    return out
 
 
 def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
@@ -150,15 +168,18 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     """
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
-    pred = L.dev_f32(prediction, "prediction").contiguous()
-    if pred.dim() != 3 or pred.shape[2] < 6:
+    if isinstance(prediction, torch.Tensor) and (prediction.dim() != 3 or prediction.shape[2] < 6):
         raise RuntimeError(f"prediction must be (bs, A, 5+nc) with nc >= 1, got {tuple(prediction.shape)}")
+    # an fp16 tensor gets the reference's fp16 arithmetic (see _prepared_from_half); anything else is computed in fp32
+    prepared = isinstance(prediction, torch.Tensor) and prediction.is_cuda and prediction.dtype == torch.float16 \
+        and prediction.numel() > 0
+    pred = _prepared_from_half(prediction, conf_thres, labels) if prepared else L.dev_f32(prediction, "prediction").contiguous()
     bs, _, no = pred.shape
     nc = no - 5
     multi_label = bool(multi_label) and nc > 1                                      # general.py:667
     plane = None
     if labels and len(labels):
-        pred = _with_apriori_labels(pred, labels, nc)
+        pred = _with_apriori_labels(pred, labels, nc, corners=prepared)
     elif pred is prediction:
         plane = objectness_plane(prediction)          # compact obj column left behind by detect_decode, if still valid
     A = pred.shape[1]
@@ -173,14 +194,19 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     meta = torch.empty(4 * bs, dtype=torch.int32, device=dev)
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
-    key = ("nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
+    key = ("nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det, prepared)
     k_select = 0 if merge else _first_attempt(key, max_det, k_select)
     _remember(rows, key, k_select)
+    tail = (int(multi_label), int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select),
+            L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs), L.c_void_p(meta.data_ptr() + 12 * bs), L.ptr(ws),
+            ws_bytes, L.stream())
     with L.device_guard(dev):
-        L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), int(multi_label),
-                                   int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select),
-                                   L.ptr(rows), L.ptr(meta), L.c_void_p(meta.data_ptr() + 8 * bs),
-                                   L.c_void_p(meta.data_ptr() + 12 * bs), L.ptr(ws), ws_bytes, L.stream()), "dh_nms_batched")
+        if prepared:
+            L.check(lib.dh_nms_batched_prepared(L.ptr(pred), bs, A, nc, float(conf_thres), float(iou_thres), *tail),
+                    "dh_nms_batched_prepared")
+        else:
+            L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), *tail),
+                    "dh_nms_batched")
         if merge:
             _merge(lib, rows, meta, bs, nc, cap, max_det, iou_thres, agnostic, ws, ws_bytes)
     return rows, meta, cap

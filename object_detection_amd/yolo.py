@@ -73,13 +73,20 @@ def _anchor_pixels(anchors, stride):
     return made
 
 
-def detect_decode(levels, anchors, stride):
+def detect_decode(levels, anchors, stride, half_arithmetic=False, inplace=True):
     """Inference decode of raw head maps -> (bs, sum na*ny*nx, no)  (yolo.py:56-70).
 
     levels: list of (bs,na,ny,nx,no) tensors; anchors: (nl,na,2) in grid units; stride: (nl,).
     One kernel launch covers every level and writes the concatenated tensor directly.
+    fp16 maps are widened on load and decoded in fp32 to an fp32 tensor, unless half_arithmetic is set: then the result is
+    the fp16 tensor a half-precision model computes (model.half(), val.py:129-130), rounding for rounding -- or, with
+    inplace=False, the fp32 tensor its torch.cat form yields (yolo.py:63-65).
     """
     xs, half = L.head_maps(levels)
+    if half_arithmetic:
+        if not half:
+            raise RuntimeError("detect_decode(half_arithmetic=True) needs fp16 maps")
+        return _detect_decode_half(xs, anchors, stride, inplace)
     nl = len(xs)
     bs, na, _, _, no = xs[0].shape
     for x in xs:
@@ -99,6 +106,30 @@ def detect_decode(levels, anchors, stride):
         L.check(entry(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
                       L.ptr(out), L.ptr(plane), L.ptr(logits), L.c_void_p(made_on)), "dh_yolo_decode")
     _remember_planes(out, xs, plane, logits, made_on)
+    return out
+
+
+def _detect_decode_half(xs, anchors, stride, inplace=True):
+    """yolo.py:56-70 on a half-precision model: fp16 maps in; fp16 decoded tensor out, or fp32 for the torch.cat form
+    (dh_yolo_decode_half)."""
+    nl = len(xs)
+    bs, na, _, _, no = xs[0].shape
+    for x in xs:
+        if x.dim() != 5 or x.shape[0] != bs or x.shape[1] != na or x.shape[4] != no:
+            raise RuntimeError(f"detect_decode: inconsistent level shape {tuple(x.shape)}")
+    ny = [int(x.shape[2]) for x in xs]
+    nx = [int(x.shape[3]) for x in xs]
+    total = sum(na * a * b for a, b in zip(ny, nx))
+    # anchor_grid of such a model (yolo.py:79-80): the fp16 anchors buffer times the stride, rounded to fp16, then .float()
+    svals = [float(v) for v in (stride.tolist() if isinstance(stride, torch.Tensor) else stride)]
+    anc = anchors.detach().half().cpu()
+    anchor_grid = torch.stack([(anc[l] * torch.tensor(svals[l])).float() for l in range(nl)])
+    out = torch.empty((bs, total, no), dtype=torch.float16 if inplace else torch.float32, device=xs[0].device)
+    ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
+    with L.device_guard(out.device):
+        L.check(L.lib().dh_yolo_decode_half(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no,
+                                            L.float_array(anchor_grid.reshape(-1).tolist()), L.float_array(svals), int(bool(inplace)),
+                                            L.ptr(out), None, L.stream()), "dh_yolo_decode_half")
     return out
 
 
@@ -248,6 +279,9 @@ class Detect(nn.Module):
     onnx_dynamic = False
     lazy_maps = False     # return the maps as permuted views of the convolution outputs (no copy of yolo.py:54);
     # ComputeLoss recognises them and works on the convolution outputs directly, gradients included
+    half_arithmetic = True    # a half-precision head (model.half(), val.py:129-130) returns the fp16 decoded tensor of
+    # yolo.py:56-70 with torch's fp16 roundings; False: fp16 maps are widened on load and decoded in fp32 to an fp32 tensor
+    # (one launch instead of two, closer to the fp32 model's result, not what the reference computes)
 
     def __init__(self, nc=80, anchors=(), ch=(), inplace=True):
         super().__init__()
@@ -265,7 +299,10 @@ class Detect(nn.Module):
                    max_det=300):
         """non_max_suppression(self(x)[0], ...) for callers that want nothing else from the head (detect.py:126-132,
         val.py:194-203 without compute_loss): the convolutions run as in forward, the detections come straight from
-        their outputs; neither the head maps nor the decoded tensor are made.  Same rows as the two calls, bit for bit."""
+        their outputs; neither the head maps nor the decoded tensor are made.  Same rows as the two calls, bit for bit, for an
+        fp32 head.  For an fp16 head the arithmetic here is fp32 on the widened maps, whereas self(x)[0] followed by
+        non_max_suppression reproduces the reference's fp16 roundings (half_arithmetic): scores agree to fp16 precision,
+        boxes to the fp16 spacing of their coordinates (up to 0.5 px at 640 px), and rows near a threshold can differ."""
         from .general import conv_nms
         with torch.no_grad():
             convs = [self.m[i](x[i]) for i in range(self.nl)]
@@ -291,7 +328,11 @@ class Detect(nn.Module):
                 bs, _, ny, nx = x[i].shape
                 x[i] = x[i].contiguous().view(bs, self.na, self.no, ny, nx).permute(0, 1, 3, 4, 2)
             return x
-        if self.training or torch.is_grad_enabled() and any(c.requires_grad for c in x):
+        wants_grad = torch.is_grad_enabled() and any(c.requires_grad for c in x)
+        if not self.training and not wants_grad and self.half_arithmetic and all(c.is_cuda and c.dtype == torch.float16 for c in x):
+            x[:] = head_maps(x, self.na)
+            return detect_decode(x, self.anchors, self.stride, half_arithmetic=True, inplace=self.inplace), x
+        if self.training or wants_grad:
             x[:] = head_maps(x, self.na)
             return x if self.training else (detect_decode(x, self.anchors, self.stride), x)
         z, x[:] = head_maps_decode(x, self.na, self.anchors, self.stride, lazy=self.lazy_maps)

@@ -39,11 +39,14 @@ def head_maps(convs, na):
     return out
 
 
-def detect_decode(levels, anchors, strides):
+def detect_decode(levels, anchors, strides, inplace=True):
     """Inference branch of Detect.forward (yolo.py:56-70), input already (bs,na,ny,nx,no).
 
     xy=(2s-0.5+grid)*stride, wh=(2s)^2*(anchor*stride), rest = sigmoid; levels are
-    flattened (anchor, gy, gx) and concatenated in level order.
+    flattened (anchor, gy, gx) and concatenated in level order.  The same torch operations in the same order and
+    with the same operand types as the reference (float grid and anchor grid, yolo.py:78-80), so fp16 levels and
+    anchors give what a half-precision model gives; inplace=False is the torch.cat form (yolo.py:63-65), which
+    only differs from the slice assignment in that case.
     """
     flat = []
     for lvl, x in enumerate(levels):
@@ -53,8 +56,13 @@ def detect_decode(levels, anchors, strides):
         stride = torch.as_tensor(strides[lvl], dtype=torch.float32)
         awh = (anchors[lvl].clone() * stride).view(1, na, 1, 1, 2).expand(1, na, ny, nx, 2).float()
         y = x.sigmoid()
-        y[..., 0:2] = (y[..., 0:2] * 2 - 0.5 + cell) * stride                   # yolo.py:62
-        y[..., 2:4] = (y[..., 2:4] * 2) ** 2 * awh                              # yolo.py:63
+        if inplace:
+            y[..., 0:2] = (y[..., 0:2] * 2 - 0.5 + cell) * stride               # yolo.py:59
+            y[..., 2:4] = (y[..., 2:4] * 2) ** 2 * awh                          # yolo.py:60
+        else:
+            xy = (y[..., 0:2] * 2 - 0.5 + cell) * stride                        # yolo.py:63
+            wh = (y[..., 2:4] * 2) ** 2 * awh                                   # yolo.py:64
+            y = torch.cat((xy, wh, y[..., 4:]), -1)                             # yolo.py:65
         flat.append(y.view(bs, -1, no))
     return torch.cat(flat, 1)
 

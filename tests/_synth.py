@@ -82,3 +82,19 @@ def make_big_pred():
     big[..., 4][low] = rs.uniform(0.2, 0.5, int(low.sum()))
     big[..., 5:] = np.maximum(big[..., 5:], f32(rs.uniform(0.2, 0.4, big[..., 5:].shape)))
     return dedupe_scores(big, 0.001)
+
+
+# The half-precision fixture (tests/golden/half.npz, tools/make_golden.py gen_half): Detect cases taken from the fp32
+# fixture's list (the last one is the torch.cat form, inplace=False) and NMS calls on an fp16 prediction tensor.
+HALF_DETECT_TAGS = ("s3_nc80", "s3_nc7_rect", "s4_nc7", "s5_nc3_na2")
+
+HALF_NMS_VARIANTS = {     # thresholds that fp16 represents exactly or rounds down, except multi_001 (see gen_half)
+    "default": dict(conf_thres=0.25, iou_thres=0.45),
+    "multi": dict(conf_thres=2.0 ** -10, iou_thres=0.6, multi_label=True),
+    "multi_001": dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+    "multi_c2": dict(conf_thres=0.2, iou_thres=0.5, multi_label=True),
+    "agnostic": dict(conf_thres=0.125, agnostic=True),
+    "classes_multi": dict(conf_thres=0.0625, classes=[0, 2, 7], multi_label=True),
+    "maxdet5": dict(conf_thres=0.0625, multi_label=True, max_det=5),
+    "labels": dict(conf_thres=0.125),                                           # + the fixture's labels for images 0 and 2
+}

@@ -96,14 +96,15 @@ def test_half_and_non_contiguous_inputs():
     assert torch.equal(l16, l32)
     for a, b in zip(g16, g32):
         assert a.dtype == torch.float16 and torch.equal(a, b.half())
-    # a strided view of a wider tensor (every other anchor row) and a half-precision prediction
+    # a strided view of a wider tensor (every other anchor row) and a half-precision prediction tensor
     pred = synth_pred(rs, 2, 4000, 6, n_obj=5, k_per_obj=20)
     wide = T(pred).cuda()
     view = wide[:, ::2]
     assert not view.is_contiguous()
     same_lists(non_max_suppression(view, 0.2, 0.45), onms.non_max_suppression(T(pred)[:, ::2].clone(), 0.2, 0.45))
-    h = wide.half()
-    same_lists(non_max_suppression(h, 0.2, 0.45), onms.non_max_suppression(h.float().cpu(), 0.2, 0.45))
+    h = wide.half()              # an fp16 tensor gets the reference's fp16 products and corners (tests/test_gpu_half.py)
+    same_lists(non_max_suppression(h, 0.2, 0.45), onms.non_max_suppression(h.cpu(), 0.2, 0.45))
+    same_lists(non_max_suppression(h.float(), 0.2, 0.45), onms.non_max_suppression(h.float().cpu(), 0.2, 0.45))
 
 
 @pytest.mark.parametrize("shapes,nc", [(((20, 20), (10, 10), (5, 5)), 80), (((7, 5), (3, 3)), 1), (((9, 11), (4, 6), (2, 3)), 130)])

@@ -1,0 +1,112 @@
+"""The reference's half-precision inference path on the GPU (model.half(), val.py:129-130): Detect's decode with torch's
+fp16 roundings and non_max_suppression on an fp16 prediction tensor, against the fixture the reference's own code produced
+(tests/golden/half.npz) and against the oracle on larger inputs.
+
+NMS: bit-exact (fp16 products and corners are exactly rounded operations; everything after them is the fp32 pipeline).
+Decode: the sigmoid is evaluated in fp32 and rounded to fp16; the kernel's fp32 sigmoid (hardware exp and reciprocal)
+differs from torch's in its last bits, which moves the fp16 rounding of about one value in a thousand by one fp16 ulp; a
+box coordinate derived from such a value moves by a few ulps of its own rounding.  The test bounds both: every element
+within one fp16 ulp (two for xy, six for wh), at most 0.5 % of the elements different at all."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms as onms
+from oracle import yolo as oy
+from tests._synth import HALF_DETECT_TAGS, HALF_NMS_VARIANTS, synth_head, synth_pred
+from tests.test_gpu_nms import same_lists
+from tests.test_oracle_golden import half_nms_kwargs, unpack
+
+pytestmark = pytest.mark.gpu
+
+
+def half_ulp(v):
+    """Spacing of fp16 at |v| (fp32 array in, fp32 out)."""
+    a = np.maximum(np.abs(v.astype(np.float32)), np.float32(2.0 ** -14))
+    return np.exp2(np.floor(np.log2(a)) - 10).astype(np.float32)
+
+
+def decoded_half_close(got, want, no, inplace):
+    """One fp16 ulp of the sigmoid is a relative 2^-10 at worst; xy keeps it below one ulp of its own rounding, the square
+    in wh doubles it (up to four ulps of the squared value) before wh's own roundings."""
+    got, want = got.astype(np.float32), want.astype(np.float32)
+    err = np.abs(got - want) / half_ulp(want)
+    ch = np.arange(got.shape[-1])
+    limit = np.where(ch < 2, 2.0, np.where(ch < 4, 6.0, 1.0))
+    assert (err <= limit).all(), float(err.max())
+    assert (got != want).mean() < 0.005, float((got != want).mean())
+
+
+@pytest.mark.parametrize("tag", HALF_DETECT_TAGS)
+def test_half_decode_against_the_reference_fixture(golden, tag):
+    from object_detection_amd import yolo
+    g = golden("half")
+    nc, na, nl, inplace, bs = (int(v) for v in g[f"{tag}_meta"])
+    convs = [torch.from_numpy(g[f"{tag}_conv{l}"]).cuda() for l in range(nl)]
+    anchors = torch.from_numpy(g[f"{tag}_anchors"]).cuda()
+    strides = torch.from_numpy(g[f"{tag}_strides"])
+    maps = yolo.head_maps(convs, na)
+    z = yolo.detect_decode(maps, anchors, strides, half_arithmetic=True, inplace=bool(inplace))
+    assert z.dtype == (torch.float16 if inplace else torch.float32) and tuple(z.shape) == g[f"{tag}_z"].shape
+    decoded_half_close(z.cpu().numpy(), g[f"{tag}_z"], nc + 5, bool(inplace))
+    # the module: same tensor from the convolution inputs' side (its own convolutions replaced by the fixture's outputs)
+    det = yolo.Detect(nc=nc, anchors=[[1.0] * (2 * na)] * nl, ch=[1] * nl, inplace=bool(inplace)).cuda().half().eval()
+    det.anchors.copy_(anchors)
+    det.stride = strides
+    det.m = torch.nn.ModuleList(torch.nn.Identity() for _ in range(nl))
+    zz, xs = det([c.clone() for c in convs])
+    assert zz.dtype == z.dtype and torch.equal(zz, z)
+    for x, m in zip(xs, maps):
+        assert x.dtype == torch.float16 and torch.equal(x, m)
+    det.half_arithmetic = False                     # opt-out: fp32 arithmetic on the widened maps
+    z32, _ = det([c.clone() for c in convs])
+    assert z32.dtype == torch.float32 and torch.equal(z32, yolo.detect_decode(maps, anchors, strides))
+
+
+@pytest.mark.parametrize("tag", list(HALF_NMS_VARIANTS))
+def test_half_nms_against_the_reference_fixture(golden, tag):
+    from object_detection_amd.general import non_max_suppression
+    g = golden("half")
+    kw = half_nms_kwargs(g, tag)
+    got = non_max_suppression(torch.from_numpy(g["nms_pred"]).cuda(), **kw)
+    assert all(d.dtype == torch.float32 for d in got)
+    same_lists(got, unpack(g, "nms_" + tag))
+
+
+@pytest.mark.parametrize("kw", [dict(conf_thres=0.25, iou_thres=0.45), dict(conf_thres=2.0 ** -10, iou_thres=0.6, multi_label=True),
+                                dict(conf_thres=0.03125, iou_thres=0.5, agnostic=True, max_det=1000),
+                                dict(conf_thres=0.0625, iou_thres=0.3, multi_label=True, classes=[1, 3, 5, 79], max_det=50)])
+def test_half_nms_bs4_25200_vs_oracle(kw):
+    """fp16 prediction tensor of the 640 px head's shape; the oracle runs the reference's torch operations on the CPU."""
+    from object_detection_amd.general import non_max_suppression
+    rs = np.random.RandomState(211)
+    pred = synth_pred(rs, 4, 25200, 80, n_obj=12, k_per_obj=40).astype(np.float16)
+    want = onms.non_max_suppression(torch.from_numpy(pred).clone(), **kw)
+    got = non_max_suppression(torch.from_numpy(pred).cuda(), **kw)
+    same_lists(got, want)
+    assert sum(w.shape[0] for w in want) > 50
+    # fp32 arithmetic on the widened tensor is a different computation: scores differ in the bits fp16 drops
+    wide = non_max_suppression(torch.from_numpy(pred).cuda().float(), **kw)
+    assert any(a.shape != b.shape or not torch.equal(a, b) for a, b in zip(wide, got))
+
+
+def test_half_decode_then_nms_640():
+    """A half-precision head end to end at bs 8 @ 640 px: decode with fp16 roundings, NMS on the fp16 tensor; the oracle
+    runs on the decoded tensor the kernel produced (NMS exact), the decode is checked against the oracle's."""
+    from object_detection_amd.general import non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    rs = np.random.RandomState(5)
+    levels = synth_head(rs, 8, 640, 80)
+    for x in levels:
+        m = rs.uniform(0, 1, x.shape[:-1]) < 0.01
+        x[m, 4] = rs.normal(1.0, 1.0, int(m.sum()))
+        x[m, 5 + rs.randint(0, 80)] = 2.0
+    half = [torch.from_numpy(x).half() for x in levels]
+    anchors, strides = oy.grid_anchors(), torch.tensor(oy.YOLOV5S_STRIDES)
+    z = detect_decode([h.cuda() for h in half], anchors.cuda(), strides, half_arithmetic=True)
+    want_z = oy.detect_decode(half, anchors.half(), oy.YOLOV5S_STRIDES)
+    decoded_half_close(z.cpu().numpy(), want_z.numpy(), 85, True)
+    for kw in (dict(conf_thres=0.25, iou_thres=0.45), dict(conf_thres=2.0 ** -10, iou_thres=0.6, multi_label=True)):
+        want = onms.non_max_suppression(z.cpu().clone(), **kw)
+        same_lists(non_max_suppression(z, **kw), want)
+        assert sum(w.shape[0] for w in want) > 100

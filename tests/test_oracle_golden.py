@@ -438,3 +438,37 @@ def test_detect_head_maps_and_decode(golden, tag):
     for l, m in enumerate(maps):      # anchor_grid = anchors * stride, grid = (x, y) cell indices (yolo.py:72-81)
         assert tuple(g[f"{tag}_grid{l}"].shape) == (1, na, m.shape[2], m.shape[3], 2)
         np.testing.assert_array_equal(g[f"{tag}_anchor_grid{l}"][0, :, 0, 0], g[f"{tag}_anchors"][l] * g[f"{tag}_strides"][l])
+
+
+def half_nms_kwargs(g, tag):
+    from tests._synth import HALF_NMS_VARIANTS
+    kw = dict(HALF_NMS_VARIANTS[tag])
+    if tag == "labels":
+        kw["labels"] = [torch.from_numpy(g["nms_labels0"]), torch.zeros((0, 5)), torch.from_numpy(g["nms_labels2"])]
+    return kw
+
+
+def test_half_precision_detect_and_nms(golden):
+    """The reference's half-precision inference path (model.half(), val.py:129-130) run on the CPU by
+    tools/make_golden.py: its Detect class on fp16 maps (fp16 result; fp32 for the torch.cat form) and its
+    non_max_suppression on an fp16 prediction tensor (fp16 products and corners, fp32 rows).  The oracle's functions are
+    the same torch operations in the same order on the same operand types: bit-exact."""
+    from tests._synth import HALF_DETECT_TAGS, HALF_NMS_VARIANTS
+    g = golden("half")
+    for tag in HALF_DETECT_TAGS:
+        nc, na, nl, inplace, bs = (int(v) for v in g[f"{tag}_meta"])
+        convs = [torch.from_numpy(g[f"{tag}_conv{l}"]) for l in range(nl)]
+        assert all(c.dtype == torch.float16 for c in convs)
+        z = oy.detect_decode(oy.head_maps(convs, na), torch.from_numpy(g[f"{tag}_anchors"]), [float(s) for s in g[f"{tag}_strides"]],
+                             inplace=bool(inplace))
+        assert z.dtype == (torch.float16 if inplace else torch.float32)
+        np.testing.assert_array_equal(z.numpy(), g[f"{tag}_z"])
+    pred = torch.from_numpy(g["nms_pred"])
+    assert pred.dtype == torch.float16
+    for tag in HALF_NMS_VARIANTS:
+        got = onms.non_max_suppression(pred.clone(), **half_nms_kwargs(g, tag))
+        want = unpack(g, "nms_" + tag)
+        assert [int(d.shape[0]) for d in got] == [w.shape[0] for w in want], tag
+        for d, w in zip(got, want):
+            assert d.dtype == torch.float32
+            np.testing.assert_array_equal(d.numpy(), w)

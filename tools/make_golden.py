@@ -82,7 +82,7 @@ def load_reference():
 
 
 from tests._synth import (f32, rand_boxes_xywh, synth_targets, synth_head, synth_pred, dedupe_scores,  # noqa: E402
-                          make_big_pred)
+                          make_big_pred, HALF_DETECT_TAGS, HALF_NMS_VARIANTS)
 
 
 def T(a):
@@ -699,6 +699,71 @@ def gen_detect(y_general):
     save("detect", **out)
 
 
+def half_nms_inputs():
+    """fp16 prediction tensor and apriori labels of the half-precision NMS fixture (rebuilt by the tests)."""
+    rs = np.random.RandomState(83)
+    pred = synth_pred(rs, 3, 1008, 16).astype(np.float16)
+    pred[1, 5, 4] = 0.25                                                  # objectness exactly at a threshold -> rejected
+    # conf_thres 0.001 becomes 0.0010004 when rounded to fp16: a CPU comparison of an fp16 tensor with that scalar uses the
+    # rounded value, a device kernel the fp32 one, and the two disagree on a score that is exactly 0.0010004.  The reference
+    # runs fp16 on devices only (val.py:129); keep such scores out of the inputs so that the fixture holds for both.
+    edge = np.float16(0.001)
+    prod = (pred[..., 5:].astype(np.float32) * pred[..., 4:5].astype(np.float32)).astype(np.float16)
+    pred[..., 5:][prod == edge] = 0
+    pred[..., 4][pred[..., 4] == edge] = 0
+    labels = [T([[3, 100, 100, 50, 60], [5, 300, 310, 80, 40]]), torch.zeros((0, 5)), T([[1, 200, 200, 90, 90]])]
+    return pred, labels
+
+
+def gen_half(y_general):
+    """The reference's half-precision inference path (model.half(), val.py:129-130), run on the CPU: Detect's inference
+    branch on fp16 maps (yolo.py:56-70) and non_max_suppression on an fp16 prediction tensor (general.py:647-738)."""
+    from oracle import yolo as oy
+    Detect = reference_detect_class(y_general)
+    out = {}
+    for tag in HALF_DETECT_TAGS:
+        nc, anchors_px, strides, ch, hw, bs, inplace = DETECT_CASES[tag]
+        anchors_px = anchors_px or oy.YOLOV5S_ANCHORS_PX
+        torch.manual_seed(sum(map(ord, tag)))
+        det = Detect(nc=nc, anchors=anchors_px, ch=ch, inplace=inplace)
+        det.stride = torch.tensor([float(s) for s in strides])
+        det.anchors /= det.stride.view(-1, 1, 1)                                   # yolo.py:113
+        with torch.no_grad():
+            for m, s in zip(det.m, strides):                                       # yolo.py:196-204
+                b = m.bias.view(det.na, -1)
+                b[:, 4] += np.log(8 / (640 / s) ** 2)
+                b[:, 5:] += np.log(0.6 / (nc - 0.999999))
+                m.weight.mul_(3.0)
+        det.half().eval()                                                          # val.py:130
+        feats = [T(x).half() for x in detect_case_inputs(tag)]
+        with torch.no_grad():
+            convs = [m(x) for m, x in zip(det.m, feats)]
+            z, maps = det([x.clone() for x in feats])
+        assert all(m.dtype == torch.float16 for m in maps) and z.dtype == (torch.float16 if inplace else torch.float32), tag
+        assert det.anchors.dtype == torch.float16 and det.stride.dtype == torch.float32 and det.anchor_grid[0].dtype == torch.float32
+        mine = oy.detect_decode(oy.head_maps(convs, det.na), det.anchors, [float(s) for s in strides], inplace=inplace)
+        assert mine.dtype == z.dtype and torch.equal(mine, z), tag
+        out[f"{tag}_anchors"] = det.anchors.numpy().copy()                         # fp16
+        out[f"{tag}_meta"] = np.array([nc, det.na, det.nl, int(inplace), bs])
+        out[f"{tag}_strides"] = np.array(strides, dtype=np.float32)
+        out[f"{tag}_z"] = z.numpy()
+        for l in range(det.nl):
+            out[f"{tag}_conv{l}"] = convs[l].numpy()                               # fp16
+        print(f"  half detect {tag}: z {tuple(z.shape)} {z.dtype}")
+    pred, labels = half_nms_inputs()
+    out["nms_pred"] = pred
+    out["nms_labels0"], out["nms_labels2"] = labels[0].numpy(), labels[2].numpy()
+    for tag, kw in HALF_NMS_VARIANTS.items():
+        if tag == "labels":
+            kw = dict(kw, labels=labels)
+        NMS_CALLS.clear()
+        dets = y_general.non_max_suppression(torch.from_numpy(pred).clone(), **kw)
+        assert all(d.dtype == torch.float32 for d in dets)
+        pack_list(out, "nms_" + tag, dets)
+        print(f"  half nms {tag}: {[d.shape[0] for d in dets]}")
+    save("half", **out)
+
+
 def ap_case(rs, n, nc, n_lab, niou=10, p_hit=0.6, absent=()):
     """Evaluation statistics as val.py collects them: tp (n, niou) bool (a hit at a higher IoU threshold implies the
     lower ones, at most one hit per label), conf (n,) float32 all different, pred_cls (n,) float32, target_cls (m,) float64."""
@@ -860,7 +925,7 @@ def main():
     only = set(sys.argv[1:])
     if only:                      # e.g. `make_golden.py ap`: regenerate the named fixtures only
         gens = {"ap": lambda: gen_ap(y_metrics), "evalmatch": lambda: gen_evalmatch(y_metrics), "tta": gen_tta,
-                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss), "nms_merge": lambda: gen_nms_merge(y_general), "detect": lambda: gen_detect(y_general)}
+                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss), "nms_merge": lambda: gen_nms_merge(y_general), "detect": lambda: gen_detect(y_general), "half": lambda: gen_half(y_general)}
         for k in only:
             gens[k]()
         return
@@ -875,6 +940,7 @@ def main():
     gen_evalmatch(y_metrics)
     gen_tta()
     gen_detect(y_general)
+    gen_half(y_general)
     gen_ap(y_metrics)
     gen_autoanchor()
     gen_focal(a_loss)
