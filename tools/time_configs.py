@@ -80,7 +80,13 @@ def main():
             ms_h, _ = wall(lambda: detect_nms(half, anchors, strides, **kw), args.iters)
             ms_c, _ = wall(lambda: detect_nms([h.float() for h in half], anchors, strides, **kw), args.iters)
             print(f"val   bs64@640 fused detect_nms({name}) on fp16 maps: read directly {ms_h:8.3f} ms, converted first {ms_c:8.3f} ms", flush=True)
-        del levels, z, half
+        # the reference's own fp16 arithmetic (a half-precision model, val.py:129-130): fp16 decoded tensor, NMS on it
+        ms_d, zh = wall(lambda: detect_decode(half, anchors, strides, half_arithmetic=True), args.iters)
+        for kw, name in ((dict(conf_thres=0.25, iou_thres=0.45), "0.25,0.45"), (dict(conf_thres=0.001, iou_thres=0.6, multi_label=True), "0.001,0.6,ml")):
+            ms_n, _ = wall(lambda: non_max_suppression(zh, **kw), args.iters)
+            print(f"val   bs64@640 fp16 arithmetic as the reference's half model: decode {ms_d:8.3f} ms, NMS({name}) on the fp16 tensor {ms_n:8.3f} ms",
+                  flush=True)
+        del levels, z, half, zh
     if "dense" in which:
         pred = dense_pred(32, 100000, 80, dev)
         ms, out = wall(lambda: non_max_suppression(pred, 0.25, 0.45, max_det=300), args.iters)
