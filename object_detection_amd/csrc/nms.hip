@@ -23,6 +23,16 @@
 //   6 collect     ballot/prefix-scan compaction of kept ranks in rank order, first max_det rows out
 // Cross-class pairs are skipped only when the image's coordinate range proves they cannot intersect
 // after the 7680-px class offset; otherwise that image is handled as one segment with per-box offsets.
+//
+// Those six stages are the general path.  What a call usually takes (chosen by k_select, see nms_run) is shorter:
+//   1'  the candidate search at validation thresholds streams the tensor (k_nms_prefilter_stream), and from the outputs of
+//       the head's convolutions it walks class planes (k_nms_prefilter_conv);
+//   2-6 few candidates per image: one workgroup per image does stages 2-6 in LDS (k_nms_small);
+//       thousands per image, class-aware: several workgroups per image, each with a share of the classes, select the best
+//       few thousand keys, sort, fetch boxes and run the greedy scans in one launch, a second launch ranks what they kept
+//       (k_nms_groups, k_nms_groups_final);
+//       otherwise the best k_select keys are selected and sorted in LDS (k_select_sort) ahead of stages 3-6.
+// Each of them is exact for the rows it returns or flags the image (needs_full) for the next, more general attempt.
 #include <mutex>
 
 #include "dh_common.h"
@@ -1574,7 +1584,9 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
 //      every class becomes a contiguous list in score order (equal scores: ascending anchor, the reference's candidate order);
 //   c  it fetches the boxes, runs greedy NMS per list (long lists by the whole workgroup one after another, short ones
 //      by single waves side by side) and appends the kept rows to the image's list in global memory;
-//   d  the workgroup of the image that finishes last picks the first max_det kept rows in score order and writes them.
+//   d  a second launch (k_nms_groups_final, one workgroup per image) picks the first max_det kept rows in score order and
+//      writes them: the kernel boundary makes every workgroup's rows visible, which inside one launch would take an
+//      agent-scope fence across the non-coherent L2s and cost more than the boundary does.
 // needs_full[b] = 1, as after k_select_sort: the prefix did not yield max_det rows.  needs_full[b] = 2: the image is left
 // to the separate launches (too many equal scores for the cut, more than max_nms keys selected, or a box outside the
 // window in which the class offset alone rules out overlap across classes).
