@@ -9,13 +9,11 @@
 // 100 trapezoids, so the results are the reference's bit for bit when the confidences are all different.  Detections of
 // one class with equal confidence keep their input order (the reference's unstable sort may order them either way).
 //
-// Layout: detections get 64-bit keys [class | ~order(conf)] and are sorted once (rocPRIM radix sort, stable); each class
+// Layout: detections get 64-bit keys [class | ~order(conf)] and are sorted once (the radix sort below, stable); each class
 // is then a contiguous run in descending confidence.  One workgroup per (class, IoU threshold) scans its run forwards
 // (cumulative tp) and backwards (precision envelope) through workspace arrays, then interpolates.
 #include "dh_common.h"
 #include "../../include/dethead.h"
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -108,7 +106,7 @@ __global__ void __launch_bounds__(256) k_ap_keys(const float* __restrict__ conf,
     const float c = pred_cls[i];
     const int ci = (int)c;
     const bool ok = c == (float)ci && ci >= 0 && ci < class_cap;
-    keys[i] = ((u64)(ok ? (uint32_t)ci : 0xFFFFFFFFu) << 32) | conf_desc_bits(conf[i]);
+    keys[i] = ((u64)(ok ? (uint32_t)ci : (uint32_t)class_cap) << 32) | conf_desc_bits(conf[i]);    // class_cap: behind every class
     vals[i] = (int)i;
 }
 
@@ -329,6 +327,133 @@ __global__ void __launch_bounds__(AP_THREADS) k_ap_final(const double* __restric
     }
 }
 
+// ---- radix sort -----------------------------------------------------------------------------------------------------------
+// Least-significant-digit radix sort of (key, value) pairs, 8 bits per pass, stable.  A pass is three launches: every
+// workgroup counts the digits of its tile of RS_TILE keys; one workgroup turns the (digit, workgroup) counts into
+// exclusive offsets (digit-major: all of digit 0's tiles, then digit 1's, ...); every workgroup goes over its tile again,
+// 256 keys at a time in input order, ranks each key among the equal digits before it (within the wave by ballots, across
+// waves and earlier chunks through LDS counters) and writes it to its digit's offset plus its rank.
+#define RS_THREADS 256
+#define RS_CHUNKS 16
+#define RS_TILE (RS_THREADS * RS_CHUNKS)
+
+__global__ void __launch_bounds__(RS_THREADS) k_rs_count(const u64* __restrict__ keys, long n, int shift, uint32_t* __restrict__ hist,
+                                                         uint32_t nwg)
+{
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const long first = (long)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int c = 0; c < RS_CHUNKS; ++c) {
+        const long i = first + c * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nwg + blockIdx.x] = s_h[threadIdx.x];
+}
+
+// exclusive prefix sum of `total` counters in place, by one workgroup
+__global__ void __launch_bounds__(AP_THREADS) k_rs_offsets(uint32_t* __restrict__ hist, size_t total)
+{
+    __shared__ uint32_t s_wave[AP_WAVES];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (size_t base = 0; base < total; base += AP_THREADS) {
+        const size_t i = base + threadIdx.x;
+        const uint32_t v = i < total ? hist[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (i < total) hist[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == AP_THREADS - 1) s_carry = before + incl;
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(RS_THREADS) k_rs_scatter(const u64* __restrict__ keys_in, const int* __restrict__ vals_in,
+                                                           u64* __restrict__ keys_out, int* __restrict__ vals_out, long n, int shift,
+                                                           const uint32_t* __restrict__ hist, uint32_t nwg)
+{
+    __shared__ uint32_t s_base[256];                 // where this tile's keys of each digit start in the output
+    __shared__ uint32_t s_cnt[RS_THREADS / 64][256]; // per chunk: keys of each digit per wave, then their offsets inside the digit
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_base[threadIdx.x] = hist[(size_t)threadIdx.x * nwg + blockIdx.x];
+    const long first = (long)blockIdx.x * RS_TILE;
+    for (int c = 0; c < RS_CHUNKS; ++c) {
+        if (first + c * RS_THREADS >= n) break;                             // workgroup-uniform
+#pragma unroll
+        for (int w = 0; w < RS_THREADS / 64; ++w) s_cnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        const long i = first + c * RS_THREADS + threadIdx.x;
+        const bool live = i < n;
+        const u64 key = live ? keys_in[i] : 0;
+        const int val = live ? vals_in[i] : 0;
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        u64 peers = __ballot(live);                                         // the live lanes of this wave with the same digit
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool one = (d >> bit) & 1u;
+            const u64 bm = __ballot(one);
+            peers &= one ? bm : ~bm;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        if (live && rank == 0) s_cnt[wave][d] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        {       // thread t owns digit t: the waves' counts become offsets behind what earlier chunks and waves put there
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < RS_THREADS / 64; ++w) {
+                const uint32_t cnt = s_cnt[w][threadIdx.x];
+                s_cnt[w][threadIdx.x] = run;
+                run += cnt;
+            }
+            const uint32_t start = s_base[threadIdx.x];
+            s_base[threadIdx.x] = start + run;
+#pragma unroll
+            for (int w = 0; w < RS_THREADS / 64; ++w) s_cnt[w][threadIdx.x] += start;
+        }
+        __syncthreads();
+        if (live) {
+            const size_t pos = (size_t)s_cnt[wave][d] + rank;
+            if (pos < (size_t)n) {                                          // always, while counts and keys agree
+                keys_out[pos] = key;
+                vals_out[pos] = val;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Sorts n pairs by the low `bits` bits of their keys; a and b are two buffers of n pairs, the input is in a.  Returns which of
+// the two holds the result (0: a, 1: b), or -1.
+int radix_sort_pairs(u64* keys_a, int* vals_a, u64* keys_b, int* vals_b, long n, int bits, uint32_t* hist, hipStream_t st)
+{
+    const uint32_t nwg = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    int where = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        const u64* ki = where ? keys_b : keys_a;
+        const int* vi = where ? vals_b : vals_a;
+        u64* ko = where ? keys_a : keys_b;
+        int* vo = where ? vals_a : vals_b;
+        hipLaunchKernelGGL(k_rs_count, dim3(nwg), dim3(RS_THREADS), 0, st, ki, n, shift, hist, nwg);
+        hipLaunchKernelGGL(k_rs_offsets, dim3(1), dim3(AP_THREADS), 0, st, hist, (size_t)256 * nwg);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nwg), dim3(RS_THREADS), 0, st, ki, vi, ko, vo, n, shift, (const uint32_t*)hist, nwg);
+        where ^= 1;
+    }
+    return dh_launch_status() == DH_OK ? where : -1;
+}
+
 size_t align256(size_t b) { return (b + 255) / 256 * 256; }
 
 struct ap_layout {
@@ -337,10 +462,7 @@ struct ap_layout {
 
 bool ap_make_layout(int64_t n, int niou, ap_layout& l)
 {
-    size_t sort_bytes = 0;
-    if (n > 0 && rocprim::radix_sort_pairs(nullptr, sort_bytes, (const u64*)nullptr, (u64*)nullptr, (const int*)nullptr,
-                                           (int*)nullptr, (size_t)n, 0, 64, (hipStream_t)0) != hipSuccess)
-        return false;
+    const size_t sort_bytes = sizeof(uint32_t) * 256 * (size_t)((n + RS_TILE - 1) / RS_TILE);     // (digit, workgroup) counters
     size_t at = 0;
     l.keys_in = at;  at += align256(sizeof(u64) * n);
     l.keys_out = at; at += align256(sizeof(u64) * n);
@@ -400,10 +522,11 @@ extern "C" int dh_ap_per_class(const uint8_t* tp, const float* conf, const float
     if (n > 0) {
         hipLaunchKernelGGL(k_ap_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, conf, pred_cls, (long)n, class_cap,
                            keys_in, vals_in);
-        size_t sort_bytes = l.sort_bytes;
-        if (rocprim::radix_sort_pairs(ws + l.sort_tmp, sort_bytes, (const u64*)keys_in, keys_out, (const int*)vals_in, vals_out,
-                                      (size_t)n, 0, 64, st) != hipSuccess)
-            return DH_ERR_LAUNCH;
+        int class_bits = 1;                                      // classes 0 .. class_cap (the last: no valid class)
+        while ((1ll << class_bits) <= (long long)class_cap) ++class_bits;
+        const int where = radix_sort_pairs(keys_in, vals_in, keys_out, vals_out, (long)n, 32 + class_bits, (uint32_t*)(ws + l.sort_tmp), st);
+        if (where < 0) return DH_ERR_LAUNCH;
+        if (where == 0) { keys_out = keys_in; vals_out = vals_in; }
     }
     ap_args a;
     a.tp = tp; a.keys = keys_out; a.vals = vals_out; a.unique = unique; a.nt = nt; a.n = (long)n; a.niou = niou; a.eps = eps;
