@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
 // keys do not fit the stage any more writes them directly).  Same key set as k_nms_prefilter on the decoded tensor:
 // sigmoid and the product obj * cls are the arithmetic of the decode followed by general.py:691.
 #define CONV_CH 16              // class planes in flight per lane on the position-parallel path
-#define CONV_DENSE 12           // candidates in a wave from which that path is taken
+#define CONV_DENSE 5            // candidates in a wave from which that path is taken
 #define CONV_STAGE 2048         // keys a workgroup gathers in LDS
 
 struct conv_blocks {
@@ -507,11 +507,16 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
             const float q = conf / obj;                               // < 1 for a candidate
             if (q > 0.0f && 1.0f - q > 1e-3f) bound = __logf(q / (1.0f - q)) - 0.01f;
         }
-        for (int c0 = 0; c0 < nc; c0 += CONV_CH) {
-            float v[CONV_CH];
+        // The class planes are walked CONV_CH at a time, the next group's loads in flight while this one is looked at.  Every
+        // lane loads, candidate or not, and a group past the last class re-reads the last plane: loads behind a condition
+        // would make the join wait for the newest load in flight instead of the oldest.
+        const uint32_t sq = min(s, hw - 1);
+        auto fetch = [&](float (&v)[CONV_CH], int c0) {
 #pragma unroll
             for (int u = 0; u < CONV_CH; ++u)      // element offsets inside one (image, anchor) stay below 2^31 (checked on the host)
-                v[u] = (cand && c0 + u < nc) ? ldf_nt(plane0 + ((uint32_t)(5 + c0 + u) * hw + s)) : 0.0f;
+                v[u] = ldf_nt(plane0 + ((uint32_t)(5 + min(c0 + u, nc - 1)) * hw + sq));
+        };
+        auto take = [&](const float (&v)[CONV_CH], int c0) {
 #pragma unroll
             for (int u = 0; u < CONV_CH; ++u) {
                 const int c = c0 + u;
@@ -530,6 +535,15 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
                     }
                 }
             }
+        };
+        float va[CONV_CH], vb[CONV_CH];
+        fetch(va, 0);
+#pragma unroll 1
+        for (int c0 = 0; c0 < nc; c0 += 2 * CONV_CH) {
+            fetch(vb, c0 + CONV_CH);
+            take(va, c0);
+            fetch(va, c0 + 2 * CONV_CH);
+            take(vb, c0 + CONV_CH);
         }
     } else {
         while (todo) {
