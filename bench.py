@@ -143,13 +143,13 @@ def load_pmc_traffic():
     return {}, None
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, script=None):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU, RCCL backend), wait
     for them and exit with their status.  This process never touches the GPU (counting devices does not initialise
     it), so nothing that has is ever replaced or forked."""
     have = torch.cuda.device_count()
     if have < n and not os.environ.get("DH_BENCH_SHARE_DEVICE"):
-        raise SystemExit(f"bench.py --gpus {n} needs {n} devices, this machine shows {have}")
+        raise SystemExit(f"{os.path.basename(script or __file__)} --gpus {n} needs {n} devices, this machine shows {have}")
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -157,7 +157,7 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + argv, env=env))
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(script or __file__)] + argv, env=env))
     rc = 0
     try:
         pending = list(procs)

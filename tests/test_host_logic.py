@@ -50,6 +50,10 @@ def test_bench_refuses_more_ranks_than_devices():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    # the harness of the 1280 px inference sweep launches its ranks the same way
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_sweep.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and f"bench_sweep.py --gpus {n} needs {n} devices" in r.stderr and r.stdout.strip() == ""
 
 
 def test_nms_attempt_order():
