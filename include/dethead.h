@@ -150,10 +150,12 @@ int dh_nms_batched(const float* pred, const float* obj_plane, int bs, int A, int
  * dh_nms_prepare_f16 does the fp16 part: pred_f16 (bs, A, 5+nc) fp16 -> out (bs, A, 5+nc) fp32 holding x1, y1, x2, y2,
  * the outcome of obj > conf_thres (1 or 0) and the conf values.  image_fp32 (optional, bs bytes): images flagged there are
  * computed in fp32 from the widened values, which is what the cat with the float label rows does to an image that has
- * apriori labels (general.py:678-684).  dh_nms_batched_prepared is dh_nms_batched on such a tensor (arguments as there). */
+ * apriori labels (general.py:678-684).  obj_plane (optional): (bs, A) floats that receive a compact copy of channel 4 of
+ * out, for dh_nms_batched_prepared to read.  dh_nms_batched_prepared is dh_nms_batched on such a tensor (arguments as
+ * there; the plane must be the one written with `pred`, or NULL). */
 int dh_nms_prepare_f16(const void* pred_f16, int bs, int A, int nc, double conf_thres, const unsigned char* image_fp32,
-                       float* out, void* stream);
-int dh_nms_batched_prepared(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres, int multi_label,
+                       float* out, float* obj_plane, void* stream);
+int dh_nms_batched_prepared(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres, int multi_label,
                             int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
                             int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
                             size_t workspace_bytes, void* stream);

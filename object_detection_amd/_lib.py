@@ -46,8 +46,8 @@ SIGNATURES = {
     "dh_nms_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dh_nms_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p, c_int, c_int,
                                c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "dh_nms_prepare_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p]),
-    "dh_nms_batched_prepared": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p, c_int, c_int,
+    "dh_nms_prepare_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dh_nms_batched_prepared": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p, c_int, c_int,
                                         c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                         c_void_p]),
     "dh_nms_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_double, c_int, c_double, c_int, c_void_p,

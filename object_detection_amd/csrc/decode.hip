@@ -217,23 +217,10 @@ namespace {
 
 __device__ __forceinline__ float dh_round_f16(float v) { return (float)(_Float16)v; }
 
-__device__ __forceinline__ float decode_box_half(const decode_level& L, uint32_t row, uint32_t c, float s)
-{
-    const uint32_t a = dh_div(row, L.plane);
-    const uint32_t cell = row - a * L.plane.d;
-    const uint32_t gy = dh_div(cell, L.nx);
-    const uint32_t gx = cell - gy * L.nx.d;
-    const float g = (float)((c & 1u) ? gy : gx);
-    const float t = s * 2.0f;                                                  // exact in fp16
-    const float xy = (dh_round_f16(t - 0.5f) + g) * L.stride;                  // yolo.py:60
-    const float wh = dh_round_f16(t * t) * L.anchor_px[2 * a + (c & 1u)];      // yolo.py:61
-    return c < 2 ? xy : wh;
-}
-
 // one thread: VEC consecutive elements of one level of one image (VEC = 4: one 8-byte load).  OUT = _Float16: the in-place
 // form (yolo.py:59-61), every value rounded into the fp16 tensor.  OUT = float: the torch.cat form (yolo.py:63-65), where
 // xy and wh stay the fp32 values they were computed as and the cat widens the fp16 rest.
-template <int VEC, typename OUT>
+template <int VEC, typename OUT, bool ALIGNED>
 __global__ void __launch_bounds__(256) k_yolo_decode_half(const decode_params P, OUT* __restrict__ out)
 {
     const int b = blockIdx.y;
@@ -252,19 +239,63 @@ __global__ void __launch_bounds__(256) k_yolo_decode_half(const decode_params P,
     OUT* __restrict__ dst = out + (size_t)b * P.per_image + L.first + (size_t)v * VEC;
     _Float16 x[VEC];
     OUT y[VEC];
-    if (VEC == 4) *reinterpret_cast<dh_h4*>(x) = __builtin_nontemporal_load(reinterpret_cast<const dh_h4*>(src));
+    typedef _Float16 dh_h8 __attribute__((ext_vector_type(8)));
+    if (VEC == 8) *reinterpret_cast<dh_h8*>(x) = __builtin_nontemporal_load(reinterpret_cast<const dh_h8*>(src));
+    else if (VEC == 4) *reinterpret_cast<dh_h4*>(x) = __builtin_nontemporal_load(reinterpret_cast<const dh_h4*>(src));
     else x[0] = src[0];
-    uint32_t row = dh_div(v * VEC, P.no), c = v * VEC - row * no;
+    const uint32_t row = dh_div(v * VEC, P.no), c0 = v * VEC - row * no;
+    float s[VEC];
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-        float s = dh_round_f16(dh_sigmoid((float)x[k]));                       // yolo.py:58
-        if (c < 4) s = decode_box_half(L, row, c, s);
-        y[k] = (OUT)s;                                                         // OUT = _Float16: the assignment into the fp16 tensor
-        if (c == 4 && P.obj_plane) P.obj_plane[(size_t)b * P.rows_per_image + L.row_first + row] = s;
-        if (++c == no) { c = 0; ++row; }
+    for (int k = 0; k < VEC; ++k) s[k] = dh_round_f16(dh_sigmoid((float)x[k]));        // yolo.py:58
+    // With no >= VEC + 3 (the host's condition for a vector) it holds box channels of at most one row: `row`, or `row + 1`
+    // when it runs over the row's end.  That row is decomposed once, not once per element.
+    if (c0 < 4 || c0 + VEC - 1 >= no) {
+        const bool next = c0 >= 4;
+        const uint32_t r = row + (next ? 1u : 0u);
+        const int k0 = next ? (int)(no - c0) : -(int)c0;                        // element of this vector where channel 0 of row r sits
+        const uint32_t a = dh_div(r, L.plane);
+        const uint32_t cell = r - a * L.plane.d;
+        const uint32_t gy = dh_div(cell, L.nx);
+        const uint32_t gx = cell - gy * L.nx.d;
+        float aw = L.anchor_px[0], ah = L.anchor_px[1];
+#pragma unroll
+        for (int q = 1; q < DH_MAX_ANCHORS; ++q)
+            if (a == (uint32_t)q) { aw = L.anchor_px[2 * q]; ah = L.anchor_px[2 * q + 1]; }
+        const float fgx = (float)gx, fgy = (float)gy;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = k - k0;
+            const float t = s[k] * 2.0f;                                               // exact in fp16
+            const float xy = (dh_round_f16(t - 0.5f) + ((c & 1) ? fgy : fgx)) * L.stride;   // yolo.py:60
+            const float wh = dh_round_f16(t * t) * ((c & 1) ? ah : aw);                 // yolo.py:61
+            if (c >= 0 && c < 4) s[k] = c < 2 ? xy : wh;
+        }
     }
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) dst[k] = y[k];                               // consecutive: merged into one store when aligned
+    for (int k = 0; k < VEC; ++k) y[k] = (OUT)s[k];                            // OUT = _Float16: the assignment into the fp16 tensor
+    if (P.obj_plane) {           // channel 4 of `row` sits at element 4 - c0 of the vector, of `row + 1` at 4 - c0 + no
+        int k4 = 4 - (int)c0;
+        uint32_t r4 = row;
+        if (k4 < 0) { k4 += (int)no; r4 = row + 1; }
+        if (k4 < VEC) {
+            float ov = s[0];
+#pragma unroll
+            for (int k = 1; k < VEC; ++k) if (k4 == k) ov = s[k];
+            P.obj_plane[(size_t)b * P.rows_per_image + L.row_first + r4] = ov;
+        }
+    }
+    if (VEC == 8 && ALIGNED) {                                                 // fp16 only: one 16-byte store
+        typedef OUT out8 __attribute__((ext_vector_type(8)));
+        const out8 y8 = {y[0], y[1], y[2], y[3], y[4 % VEC], y[5 % VEC], y[6 % VEC], y[7 % VEC]};
+        __builtin_nontemporal_store(y8, reinterpret_cast<out8*>(dst));
+    } else if (VEC == 4 && ALIGNED) {                                          // one 8-byte (fp16) or 16-byte (fp32) store
+        typedef OUT out4 __attribute__((ext_vector_type(4)));
+        const out4 y4 = {y[0], y[1], y[2], y[3 % VEC]};
+        __builtin_nontemporal_store(y4, reinterpret_cast<out4*>(dst));
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) dst[k] = y[k];
+    }
 }
 
 }  // namespace
@@ -288,16 +319,25 @@ extern "C" int dh_yolo_decode_half(const void* const* level_ptrs, const int* ny,
     if (reinterpret_cast<uintptr_t>(out) & (inplace ? 1u : 3u)) return DH_ERR_ALIGN;
     P.obj_plane = obj_plane;
     P.logit_plane = nullptr;
-    const int vec = vec4 ? 4 : 1;
+    // a vector of V elements holds the box channels of at most one row when no >= V + 3; its loads need the level spans, its
+    // single store the output spans, to start on multiples of V elements of aligned tensors
+    vec4 = vec4 && no >= 7;
+    bool st4 = vec4 && P.per_image % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & (inplace ? 7u : 15u)) == 0;
+    for (int l = 0; st4 && l < nl; ++l) st4 = P.lvl[l].first % 4 == 0;
+    bool v8 = inplace && st4 && no >= 11 && P.per_image % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    for (int l = 0; v8 && l < nl; ++l)
+        v8 = P.lvl[l].elems % 8 == 0 && P.lvl[l].first % 8 == 0 && (reinterpret_cast<uintptr_t>(level_ptrs[l]) & 15u) == 0;
+    const int vec = v8 ? 8 : (vec4 ? 4 : 1);
     uint32_t gx = 0;
     for (int l = 0; l < nl; ++l) {
         P.blocks[l] = (P.lvl[l].elems / vec + 255) / 256;
         gx += P.blocks[l];
     }
     hipStream_t st = (hipStream_t)stream;
-#define DH_DEC_HALF(V, O) hipLaunchKernelGGL((k_yolo_decode_half<V, O>), dim3(gx, bs), dim3(256), 0, st, P, (O*)out)
-    if (inplace) { if (vec4) DH_DEC_HALF(4, _Float16); else DH_DEC_HALF(1, _Float16); }
-    else { if (vec4) DH_DEC_HALF(4, float); else DH_DEC_HALF(1, float); }
+#define DH_DEC_HALF(V, O, A) hipLaunchKernelGGL((k_yolo_decode_half<V, O, A>), dim3(gx, bs), dim3(256), 0, st, P, (O*)out)
+    if (v8) DH_DEC_HALF(8, _Float16, true);
+    else if (inplace) { if (st4) DH_DEC_HALF(4, _Float16, true); else if (vec4) DH_DEC_HALF(4, _Float16, false); else DH_DEC_HALF(1, _Float16, false); }
+    else { if (st4) DH_DEC_HALF(4, float, true); else if (vec4) DH_DEC_HALF(4, float, false); else DH_DEC_HALF(1, float, false); }
 #undef DH_DEC_HALF
     return dh_launch_status();
 }

@@ -2399,46 +2399,118 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
 // a Python scalar.
 __device__ __forceinline__ float round_f16(float v) { return (float)(_Float16)v; }
 
-__global__ void __launch_bounds__(256) k_nms_prepare_f16(const _Float16* __restrict__ pred, int rows_per_image, int no, float conf,
-                                                         const unsigned char* __restrict__ image_fp32, float* __restrict__ out,
-                                                         size_t rows)
+// One thread: VEC consecutive elements of one image.  VEC = 8 (4): one 16-byte (8-byte) load, two (one) 16-byte stores; needs
+// A * no % VEC == 0 and no >= VEC + 4, so that a vector holds channels 0..4 of at most one row (`row`, or `row + 1` when it
+// runs over the row's end).
+// Every element is first treated as a class score (one multiply, one rounding); the few vectors that hold box or
+// objectness channels patch them afterwards.  plane (optional): the objectness outcomes once more, compact, (bs, A).
+template <int VEC>
+__global__ void __launch_bounds__(256) k_nms_prepare_f16(const _Float16* __restrict__ pred, uint32_t per_image, const dh_fastdiv nod,
+                                                         float conf, const unsigned char* __restrict__ image_fp32,
+                                                         float* __restrict__ out, float* __restrict__ plane)
 {
-    const int lane = threadIdx.x & 63;
-    for (size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (size_t)gridDim.x * 4) {     // one wave per row
-        const _Float16* __restrict__ p = pred + row * (size_t)no;
-        float* __restrict__ o = out + row * (size_t)no;
-        const bool wide = image_fp32 != nullptr && image_fp32[row / (size_t)rows_per_image] != 0;
-        const float obj = (float)p[4];
-        if (lane < 4) {
-            const float c = (float)p[lane & 1], sz = (float)p[2 + (lane & 1)];         // centre and size along this lane's axis
-            const float half_size = wide ? sz / 2 : round_f16(sz / 2);
-            const float v = (lane & 2) ? c + half_size : c - half_size;                 // general.py:556-559
-            o[lane] = wide ? v : round_f16(v);
-        } else if (lane == 4) {
-            o[4] = obj > conf ? 1.0f : 0.0f;                                            // general.py:656,675
+    const int b = blockIdx.y;
+    const uint32_t no = nod.d;
+    const uint32_t nvec = per_image / VEC;
+    const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+    if (VEC != 8 && v >= nvec) return;
+    if (VEC == 8 && v - (threadIdx.x & 63) >= nvec) return;                 // whole waves only: see the stores
+    const _Float16* __restrict__ p = pred + (size_t)b * per_image;         // this image's rows
+    float* __restrict__ o = out + (size_t)b * per_image + (size_t)v * VEC;
+    const bool wide = image_fp32 != nullptr && image_fp32[b] != 0;
+    const uint32_t e = (v < nvec ? v : nvec - 1) * VEC;                     // a lane past the end repeats the last vector
+    const uint32_t row = dh_div(e, nod), c0 = e - row * no;
+    _Float16 x[VEC];
+    typedef _Float16 dh_h8 __attribute__((ext_vector_type(8)));
+    if (VEC == 8) *reinterpret_cast<dh_h8*>(x) = __builtin_nontemporal_load(reinterpret_cast<const dh_h8*>(p + e));
+    else if (VEC == 4) *reinterpret_cast<dh_h4*>(x) = __builtin_nontemporal_load(reinterpret_cast<const dh_h4*>(p + e));
+    else x[0] = p[e];
+    const bool over = c0 + VEC > no;                                        // runs over into row + 1 (of the same image)
+    const float obj0 = (float)p[(size_t)row * no + 4];
+    const float obj1 = over ? (float)p[(size_t)(row + 1) * no + 4] : obj0;
+    float y[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const float val = (float)x[k] * (c0 + k >= no ? obj1 : obj0);      // general.py:691 (exact in fp32: 11 x 11 bits)
+        y[k] = wide ? val : round_f16(val);
+    }
+    if (c0 < 5 || over) {
+        const bool next = c0 >= 5;
+        const uint32_t r = row + (next ? 1u : 0u);
+        const int k0 = next ? (int)(no - c0) : -(int)c0;                    // element of this vector where channel 0 of row r sits
+        const _Float16* __restrict__ pr = p + (size_t)r * no;
+        const float obj = next ? obj1 : obj0;
+        const float bx = (float)pr[0], by = (float)pr[1], bw = (float)pr[2], bh = (float)pr[3];   // one round trip, not one per element
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int c = k - k0;
+            if (c >= 0 && c < 4) {                                          // this element's corner along axis c & 1 (general.py:556-559)
+                const float ctr = (c & 1) ? by : bx, sz = (c & 1) ? bh : bw;
+                const float half_size = wide ? sz / 2 : round_f16(sz / 2);
+                const float corner = (c & 2) ? ctr + half_size : ctr - half_size;
+                y[k] = wide ? corner : round_f16(corner);
+            } else if (c == 4) {
+                y[k] = obj > conf ? 1.0f : 0.0f;                            // general.py:656,675
+                if (plane) plane[(size_t)b * (per_image / no) + r] = y[k];
+            }
         }
-        for (int c = 5 + lane; c < no; c += 64) {
-            const float v = (float)p[c] * obj;                                          // general.py:691 (exact in fp32: 11 x 11 bits)
-            o[c] = wide ? v : round_f16(v);
+    }
+    if (VEC == 8) {
+        // A lane holds 8 consecutive floats, i.e. two 16-byte pieces 32 bytes apart from its neighbour's: stored as they are,
+        // every store instruction would fill half of each 64-byte sector.  The wave's 128 pieces are redistributed instead:
+        // store q writes pieces 64q .. 64q+63, lane i piece 64q + i, which lane 32q + i/2 holds in its half i & 1.  Every lane
+        // of the wave takes part (lanes past the end hold a repeat of the last vector and store nothing).
+        const int lane = threadIdx.x & 63;
+        float* __restrict__ wave_out = out + (size_t)b * per_image + (size_t)(v - lane) * 8;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int src = 32 * q + (lane >> 1);
+            float z[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = __shfl(y[k], src, 64), hi = __shfl(y[4 + k], src, 64);
+                z[k] = (lane & 1) ? hi : lo;
+            }
+            const uint32_t piece = 64 * q + lane;                  // of the wave's 128
+            if ((v - lane) * 2 + piece < nvec * 2) {
+                const dh_f4 z4 = {z[0], z[1], z[2], z[3]};
+                __builtin_nontemporal_store(z4, reinterpret_cast<dh_f4*>(wave_out) + piece);
+            }
         }
+    } else if (VEC == 4) {
+        const dh_f4 y4 = {y[0], y[1], y[2], y[3]};
+        __builtin_nontemporal_store(y4, reinterpret_cast<dh_f4*>(o));
+    } else {
+        o[0] = y[0];
     }
 }
 
 extern "C" int dh_nms_prepare_f16(const void* pred_f16, int bs, int A, int nc, double conf_thres, const unsigned char* image_fp32,
-                                  float* out, void* stream)
+                                  float* out, float* obj_plane, void* stream)
 {
-    if (bs < 0 || A < 0 || nc < 1) return DH_ERR_ARG;
-    const size_t rows = (size_t)bs * (size_t)A;
-    if (rows == 0) return DH_OK;
+    if (bs < 0 || bs > 65535 || A < 0 || nc < 1) return DH_ERR_ARG;
+    if (bs == 0 || A == 0) return DH_OK;
     if (!pred_f16 || !out) return DH_ERR_ARG;
-    size_t blocks = (rows + 3) / 4;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(k_nms_prepare_f16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)pred_f16, A, nc + 5,
-                       (float)conf_thres, image_fp32, out, rows);
+    const unsigned long long per_image = (unsigned long long)A * (nc + 5);
+    if (per_image >= (1ull << 31)) return DH_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(pred_f16) & 1u) return DH_ERR_ALIGN;
+    const int no = nc + 5;
+    int vec = 1;
+    if (dh_aligned16(out)) {
+        if (no >= 12 && per_image % 8 == 0 && (reinterpret_cast<uintptr_t>(pred_f16) & 15u) == 0) vec = 8;
+        else if (no >= 8 && per_image % 4 == 0 && (reinterpret_cast<uintptr_t>(pred_f16) & 7u) == 0) vec = 4;
+    }
+    const dh_fastdiv nod = dh_make_fastdiv((uint32_t)no);
+    const uint32_t nvec = (uint32_t)(per_image / vec);
+    const dim3 grid((nvec + 255) / 256, bs);
+#define DH_PREPARE(V) hipLaunchKernelGGL(k_nms_prepare_f16<V>, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)pred_f16, \
+                                         (uint32_t)per_image, nod, (float)conf_thres, image_fp32, out, obj_plane)
+    if (vec == 8) DH_PREPARE(8); else if (vec == 4) DH_PREPARE(4); else DH_PREPARE(1);
+#undef DH_PREPARE
     return dh_launch_status();
 }
 
-extern "C" int dh_nms_batched_prepared(const float* pred, int bs, int A, int nc, double conf_thres, double iou_thres,
+extern "C" int dh_nms_batched_prepared(const float* pred, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
                                        int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
                                        int max_nms, double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
                                        int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
@@ -2450,7 +2522,7 @@ extern "C" int dh_nms_batched_prepared(const float* pred, int bs, int A, int nc,
     S.no = nc + 5;
     S.conv_na = 0;
     S.corners = 1;
-    return nms_run(S, false, false, nullptr, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
+    return nms_run(S, false, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
                    max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
 

@@ -141,10 +141,11 @@ def _prepared_from_half(prediction, conf_thres, labels):
     if labels and len(labels):
         wide = torch.tensor([1 if len(l) else 0 for l in labels], dtype=torch.uint8).to(pred.device)
     out = torch.empty((bs, A, no), dtype=torch.float32, device=pred.device)
+    plane = torch.empty((bs, A), dtype=torch.float32, device=pred.device)       # channel 4 of `out` once more, compact
     with L.device_guard(pred.device):
-        L.check(L.lib().dh_nms_prepare_f16(L.ptr(pred), bs, A, no - 5, float(conf_thres), L.ptr(wide), L.ptr(out), L.stream()),
-                "dh_nms_prepare_f16")
-    return out
+        L.check(L.lib().dh_nms_prepare_f16(L.ptr(pred), bs, A, no - 5, float(conf_thres), L.ptr(wide), L.ptr(out), L.ptr(plane),
+                                           L.stream()), "dh_nms_prepare_f16")
+    return out, plane
 
 
 def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
@@ -173,13 +174,17 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     # an fp16 tensor gets the reference's fp16 arithmetic (see _prepared_from_half); anything else is computed in fp32
     prepared = isinstance(prediction, torch.Tensor) and prediction.is_cuda and prediction.dtype == torch.float16 \
         and prediction.numel() > 0
-    pred = _prepared_from_half(prediction, conf_thres, labels) if prepared else L.dev_f32(prediction, "prediction").contiguous()
+    plane = None
+    if prepared:
+        pred, plane = _prepared_from_half(prediction, conf_thres, labels)
+    else:
+        pred = L.dev_f32(prediction, "prediction").contiguous()
     bs, _, no = pred.shape
     nc = no - 5
     multi_label = bool(multi_label) and nc > 1                                      # general.py:667
-    plane = None
     if labels and len(labels):
         pred = _with_apriori_labels(pred, labels, nc, corners=prepared)
+        plane = None                                  # the label rows are not in it
     elif pred is prediction:
         plane = objectness_plane(prediction)          # compact obj column left behind by detect_decode, if still valid
     A = pred.shape[1]
@@ -202,7 +207,7 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
             ws_bytes, L.stream())
     with L.device_guard(dev):
         if prepared:
-            L.check(lib.dh_nms_batched_prepared(L.ptr(pred), bs, A, nc, float(conf_thres), float(iou_thres), *tail),
+            L.check(lib.dh_nms_batched_prepared(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), *tail),
                     "dh_nms_batched_prepared")
         else:
             L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), *tail),
