@@ -21,10 +21,19 @@ def objectness_plane(pred):
     hit = _OBJ_PLANES.get(pred.data_ptr())
     if hit is None:
         return None
-    ref, version, plane, made_on = hit
+    ref, version, plane, made_on, in_capture = hit
+    if _stale_for_capture(in_capture):
+        return None
     if ref() is pred and pred._version == version and plane.shape == pred.shape[:2]:
         return _borrow(plane, made_on)
     return None
+
+
+def _stale_for_capture(made_in_capture):
+    """A launch sequence that is being captured into a HIP graph must not read a plane an eager call wrote: the graph
+    would replay against memory whose contents and lifetime belong to that earlier call.  Planes written inside the same
+    capture live in the graph's pool and are rewritten by every replay, so they stay usable there."""
+    return (not made_in_capture) and torch.cuda.is_current_stream_capturing()
 
 
 def _borrow(plane, made_on):
@@ -45,7 +54,7 @@ def objectness_logits(maps):
     if not maps:
         return None
     hit = _LOGIT_PLANES.get(maps[0].data_ptr())
-    if hit is None or len(hit[0]) != len(maps):
+    if hit is None or len(hit[0]) != len(maps) or _stale_for_capture(hit[3]):
         return None
     for x, (ref, version, shape) in zip(maps, hit[0]):
         seen = ref()
@@ -143,8 +152,9 @@ def _remember_planes(out, xs, plane, logits, made_on):
             del registry[k]
         if len(registry) > 8:
             registry.clear()
-    _OBJ_PLANES[out.data_ptr()] = (weakref.ref(out), out._version, plane, made_on)
-    _LOGIT_PLANES[xs[0].data_ptr()] = ([(weakref.ref(x), x._version, tuple(x.shape)) for x in xs], logits, made_on)
+    in_capture = torch.cuda.is_current_stream_capturing()
+    _OBJ_PLANES[out.data_ptr()] = (weakref.ref(out), out._version, plane, made_on, in_capture)
+    _LOGIT_PLANES[xs[0].data_ptr()] = ([(weakref.ref(x), x._version, tuple(x.shape)) for x in xs], logits, made_on, in_capture)
 
 
 def _head_geometry(convs, na):
