@@ -8,5 +8,5 @@ Every function restates, in plain PyTorch-CPU / numpy / C, the arithmetic of one
 function of the reference (cited file:line in each docstring) with the same
 operation order, so fp32 results agree bit-for-bit with the reference on CPU.
 The restatement is pinned by the fixtures under ``tests/golden/`` which were
-produced by running the reference's own code (``tools/make_golden.py``).
+produced by running the reference's own code (``tests/golden/make_golden.py``).
 """

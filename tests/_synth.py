@@ -1,4 +1,4 @@
-"""Seeded synthetic inputs shared by tools/make_golden.py, the tests and bench.py.
+"""Seeded synthetic inputs shared by tests/golden/make_golden.py, the tests and bench.py.
 
 Everything is drawn from numpy's legacy ``RandomState`` (a bit-stable stream), so the
 fixtures can store outputs only and the tests can rebuild the exact inputs.
@@ -84,7 +84,7 @@ def make_big_pred():
     return dedupe_scores(big, 0.001)
 
 
-# The half-precision fixture (tests/golden/half.npz, tools/make_golden.py gen_half): Detect cases taken from the fp32
+# The half-precision fixture (tests/golden/half.npz, tests/golden/make_golden.py gen_half): Detect cases taken from the fp32
 # fixture's list (the last one is the torch.cat form, inplace=False) and NMS calls on an fp16 prediction tensor.
 HALF_DETECT_TAGS = ("s3_nc80", "s3_nc7_rect", "s4_nc7", "s5_nc3_na2")
 

@@ -2,7 +2,7 @@
 """Generate tests/golden/*.npz by running the reference's own Python code on CPU.
 
 Run in the build container only (needs /root/reference, which never travels to
-the GPU box):   python tools/make_golden.py
+the GPU box):   python tests/golden/make_golden.py
 
 How the reference is imported (no reference source is modified or copied):
   * sys.path gets /root/reference/object_detection/yolov5 and /root/reference/object_detection;
@@ -28,7 +28,7 @@ sys.dont_write_bytecode = True
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "tests", "golden")
 REF = "/root/reference/object_detection"

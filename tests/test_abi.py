@@ -42,6 +42,19 @@ def test_product_never_imports_oracle():
                 assert "oracle" not in src.replace("oracle/", ""), f"{f} mentions the oracle"
 
 
+def test_only_the_checkers_import_the_oracle():
+    """Outside tests/ the oracle is imported by bench.py (its cpu_baseline leg) and __graft_entry__.py (smoke, build) only:
+    no tool or script may lean on it."""
+    import re
+    allowed = {os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "tests", "oracle", "gpurun_out", "__pycache__")]
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py") and path not in allowed:
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", open(path).read(), re.M), f"{path} imports the oracle"
+
+
 def test_bench_cpu_baseline_leg_runs_on_the_oracle():
     """bench.py's cpu_baseline leg is the oracle on a bounded sample; it must work without a GPU."""
     import bench

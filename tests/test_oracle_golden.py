@@ -179,7 +179,7 @@ def merge_close(got, want):
 
 @pytest.mark.parametrize("tag", list(MERGE_VARIANTS))
 def test_merge_nms(golden, tag):
-    """general.py:725-731 run by the reference with its local switch set (tools/make_golden.py)."""
+    """general.py:725-731 run by the reference with its local switch set (tests/golden/make_golden.py)."""
     g = golden("nms_merge")
     merge_close(onms.non_max_suppression(T(g["pred"]).clone(), merge=True, **MERGE_VARIANTS[tag]), unpack(g, tag))
     if tag == "default":        # the step changed something: without it the result differs
@@ -426,7 +426,7 @@ DETECT_TAGS = ["s3_nc80", "s3_nc80_cat", "s3_nc7_rect", "s3_nc1", "s4_nc7", "s5_
 @pytest.mark.parametrize("tag", DETECT_TAGS)
 def test_detect_head_maps_and_decode(golden, tag):
     """Detect.forward of the reference's own class (models/yolo.py:49-81, compiled from its file by
-    tools/make_golden.py): 3 / 4 / 5 levels, nc 1 / 7 / 80, rectangular grids, both the in-place and the
+    tests/golden/make_golden.py): 3 / 4 / 5 levels, nc 1 / 7 / 80, rectangular grids, both the in-place and the
     concatenating decode.  The oracle repeats the same torch operations in the same order: bit-exact."""
     g = golden("detect")
     nc, na, nl, _, bs = (int(v) for v in g[f"{tag}_meta"])
@@ -450,7 +450,7 @@ def half_nms_kwargs(g, tag):
 
 def test_half_precision_detect_and_nms(golden):
     """The reference's half-precision inference path (model.half(), val.py:129-130) run on the CPU by
-    tools/make_golden.py: its Detect class on fp16 maps (fp16 result; fp32 for the torch.cat form) and its
+    tests/golden/make_golden.py: its Detect class on fp16 maps (fp16 result; fp32 for the torch.cat form) and its
     non_max_suppression on an fp16 prediction tensor (fp16 products and corners, fp32 rows).  The oracle's functions are
     the same torch operations in the same order on the same operand types: bit-exact."""
     from tests._synth import HALF_DETECT_TAGS, HALF_NMS_VARIANTS

@@ -126,10 +126,7 @@ def main():
             torch.autograd.grad(crit_cls(logits, label), logits)
         us2 = timed(fb_cls, args.iters)
         print(f"centernet class loss f+b   {us2:9.1f} us  bwd ~{us2 - us:8.1f} us {hb / (us2 - us) / 1e3:8.1f} GB/s (one write of the gradient maps)")
-        from oracle import focal as of       # the restatement in torch ops, run on the device: what the reference's code costs there
-        ref_cls = of.LabelSmoothingFocalLoss(num_classes=heat.shape[1], one_hot_label_format=True, gamma=8.0, smoothing=0.1)
-        us3 = timed(lambda: torch.autograd.grad(ref_cls(logits, label), logits), max(args.iters // 4, 2))
-        print(f"centernet class loss f+b   {us3:9.1f} us  as the reference's torch operations on the same device")
+        # (what the reference's torch operations cost on the same device: tests/baseline_timings.py focal)
         del heat, logits, label
         g = torch.Generator(device=dev).manual_seed(3)
         mask = (torch.rand((B, W, H), generator=g, device=dev) < 0.005).float()
