@@ -110,3 +110,43 @@ def test_half_decode_then_nms_640():
         want = onms.non_max_suppression(z.cpu().clone(), **kw)
         same_lists(non_max_suppression(z, **kw), want)
         assert sum(w.shape[0] for w in want) > 100
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_half_nms_awkward_shapes_vs_oracle(seed):
+    """Row lengths and row counts that take every load / store width of the conversion pass (8, 4 and 1 elements per thread),
+    rows that start at every offset of a vector, images with and without apriori labels, every option of the call."""
+    from object_detection_amd.general import non_max_suppression
+    rs = np.random.RandomState(9000 + seed)
+    nc = int(rs.choice([1, 2, 3, 4, 7, 11, 27, 80, 130]))
+    A = int(rs.choice([1, 7, 64, 333, 1000, 2048]))
+    bs = int(rs.choice([1, 2, 3]))
+    pred = synth_pred(rs, bs, A, nc, n_obj=min(4, A), k_per_obj=min(10, A)).astype(np.float16)
+    kw = dict(conf_thres=float(rs.choice([2.0 ** -10, 0.0625, 0.2, 0.25, 0.5])), iou_thres=float(rs.choice([0.0, 0.3, 0.45, 0.6, 1.0])),
+              agnostic=bool(rs.rand() < 0.3), multi_label=bool(rs.rand() < 0.5), max_det=int(rs.choice([1, 5, 300, 1024])))
+    if rs.rand() < 0.3:
+        kw["classes"] = sorted(set(int(c) for c in rs.randint(0, nc, 3)))
+    if rs.rand() < 0.3:
+        kw["labels"] = [torch.from_numpy(np.concatenate([rs.randint(0, nc, (n, 1)), rs.uniform(20, 600, (n, 4))], 1).astype(np.float32))
+                        for n in rs.randint(0, 4, bs)]
+    want = onms.non_max_suppression(torch.from_numpy(pred).clone(), **kw)
+    got = non_max_suppression(torch.from_numpy(pred).cuda(), **kw)
+    same_lists(got, want)
+
+
+@pytest.mark.parametrize("nc,shapes,inplace", [(1, [(5, 5), (3, 3)], True), (2, [(4, 6), (2, 3)], True), (3, [(7, 5)], False),
+                                               (6, [(8, 8), (4, 4), (2, 2)], True), (7, [(9, 11), (4, 6), (2, 3)], False),
+                                               (11, [(8, 8), (4, 4)], True), (80, [(20, 20), (10, 10), (5, 5)], True),
+                                               (130, [(6, 10), (3, 5)], True)])
+def test_half_decode_awkward_shapes_vs_oracle(nc, shapes, inplace):
+    """Row lengths below and above what the 4- and 8-element vectors need, level sizes that are not multiples of them."""
+    from object_detection_amd.yolo import detect_decode
+    rs = np.random.RandomState(nc)
+    na, bs = 3, 2
+    anchors = torch.from_numpy(rs.uniform(1.0, 6.0, (len(shapes), na, 2)).astype(np.float32))
+    strides = [8.0 * 2 ** i for i in range(len(shapes))]
+    half = [torch.from_numpy(rs.normal(0, 1.5, (bs, na, ny, nx, nc + 5)).astype(np.float32)).half() for ny, nx in shapes]
+    want = oy.detect_decode([h.clone() for h in half], anchors.half(), strides, inplace=inplace)
+    got = detect_decode([h.cuda() for h in half], anchors.cuda(), torch.tensor(strides), half_arithmetic=True, inplace=inplace)
+    assert got.dtype == want.dtype and got.shape == want.shape
+    decoded_half_close(got.cpu().numpy(), want.numpy(), nc + 5, inplace)
