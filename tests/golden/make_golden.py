@@ -147,7 +147,7 @@ def gen_bbox_iou(y_metrics, a_loss):
     b1 = T(xywh_to_xyxy_np(p.reshape(-1, 4)).reshape(3, 20, 4))
     out["lastdim_xyxy_ciou_out"] = a_loss.bbox_iou(b1, T(xywh_to_xyxy_np(t.reshape(-1, 4)).reshape(3, 20, 4)),
                                                    x1y1x2y2=True, CIoU=True).numpy()
-    # sanity vector quoted in the survey
+    # one hand-checkable pair (CIoU of two nearby boxes given as centre and size)
     v = y_metrics.bbox_iou(T([[.5, .5, .2, .3]]).T, T([[.52, .48, .25, .28]]), x1y1x2y2=False, CIoU=True)
     out["sanity_ciou"] = v.numpy()
     save("bbox_iou", **out)
