@@ -182,8 +182,8 @@ def spawn_ranks(n, argv, script=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)      # 200 steps are < 0.1 s: enough to amortise the empty pipeline
-    ap.add_argument("--warmup", type=int, default=20)      # at the start of the timed region (its first step costs two)
+    ap.add_argument("--steps", type=int, default=1000)     # a third of a second: box-to-box spread of a 200-step run was 5 %
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2, 3),
@@ -290,9 +290,9 @@ def main():
     overlap = n_streams > 1
     torch.cuda.synchronize()
     if overlap:      # keep the legacy null stream (which the runtime orders against every other stream) out of the loop
-        torch.cuda.set_stream(torch.cuda.Stream())
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ.get("DH_BENCH_MAIN_PRIORITY", "0"))))
     main_stream = torch.cuda.current_stream()
-    nms_stream = torch.cuda.Stream() if overlap else main_stream
+    nms_stream = torch.cuda.Stream(priority=int(os.environ.get("DH_BENCH_NMS_PRIORITY", "0"))) if overlap else main_stream
     loss_stream = torch.cuda.Stream() if n_streams == 3 else main_stream
     early = overlap and not args.autograd and args.early_positives
     pos_stream = torch.cuda.Stream(priority=int(os.environ.get("DH_BENCH_POS_PRIORITY", "0"))) if early else None
