@@ -17,12 +17,15 @@ namespace {
 
 #define BT_THREADS 1024
 #define BT_CHUNKS 2       // rows per thread that the single-sweep expansion keeps in registers
+#define BT_LDS_T 1024     // targets kept in LDS (24 KB): every later read of a target is then an LDS read
+#define BT_LDS_Q 4096     // (anchor, target) pairs whose stage-1 list stays in LDS instead of going through global memory
 
 struct bt_params {
     int ny[DH_MAX_LEVELS];
     int nx[DH_MAX_LEVELS];
     int nl, na;
     int nt;
+    dh_fastdiv ntd;   // nt
     float anchor_t;
     long cap;   // rows reserved per level = 5*na*nt
 };
@@ -49,15 +52,17 @@ __device__ __forceinline__ int block_rank(bool flag, int& total, int (*s_w)[BT_T
     return before + __popcll(m & ((1ull << lane) - 1ull));
 }
 
-// torch.remainder(x, 1) for fp32 (fmod, then shift a negative result up by the divisor)
+// torch.remainder(x, 1) for fp32: fmod(x, 1), then a negative result is shifted up by the divisor.  fmod(x, 1) is
+// x - trunc(x), which fp32 forms exactly (the fraction bits of x), so no general fmod is needed: the kernel is one
+// workgroup per level and bound by the instructions its 16 waves issue on one compute unit.
 __device__ __forceinline__ float remainder_one(float x)
 {
-    float m = fmodf(x, 1.0f);
+    float m = x - truncf(x);
     if (m != 0.0f && m < 0.0f) m += 1.0f;
     return m;
 }
 
-__global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __restrict__ targets,
+__global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* targets,
                                                               const float* __restrict__ anchors, const bt_params P,
                                                               int* __restrict__ list_ws, long long* __restrict__ idx,
                                                               float* __restrict__ tbox, float* __restrict__ anch,
@@ -66,17 +71,30 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
 {
     __shared__ int s_w[2][BT_THREADS / 64];
     int phase = 0;
-    if ((int)blockIdx.x >= P.nl) {      // side duty of the same launch: set a caller's region to all ones (16 B per store)
+    if ((int)blockIdx.x >= 5 * P.nl) {  // side duty of the same launch: set a caller's region to all ones (16 B per store)
         const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        const size_t step = (size_t)(gridDim.x - P.nl) * BT_THREADS;
-        for (size_t i = (size_t)(blockIdx.x - P.nl) * BT_THREADS + threadIdx.x; i < fill_vecs; i += step) fill[i] = ones;
+        const size_t step = (size_t)(gridDim.x - 5 * P.nl) * BT_THREADS;
+        for (size_t i = (size_t)(blockIdx.x - 5 * P.nl) * BT_THREADS + threadIdx.x; i < fill_vecs; i += step) fill[i] = ones;
         return;
     }
-    const int l = blockIdx.x;
+    // Five workgroups per level, one per neighbour offset: each repeats the (cheap) ratio test and the counting of all five
+    // offsets, which tells it where its own offset's rows start, and writes only those rows -- the row stores of a level
+    // then leave from five compute units instead of one.
+    const int l = blockIdx.x / 5, my_off = blockIdx.x - 5 * l;
     const int nx = P.nx[l], ny = P.ny[l];
     const float fnx = (float)nx, fny = (float)ny;
     const int total_q = P.na * P.nt;
-    int* __restrict__ list = list_ws + (size_t)l * total_q;
+    // The kernel is one workgroup per level and nothing but dependent steps: what it reads more than once comes from LDS
+    // when it fits (the usual case), so that the only global round trips are the first read of the targets and the stores.
+    __shared__ float s_targets[BT_LDS_T * 6];
+    __shared__ int s_list[BT_LDS_Q];
+    const float* targets_in = targets;
+    if (P.nt <= BT_LDS_T) {
+        for (int i = threadIdx.x; i < P.nt * 6; i += BT_THREADS) s_targets[i] = targets_in[i];
+        __syncthreads();
+        targets = s_targets;
+    }
+    int* list = total_q <= BT_LDS_Q ? s_list : list_ws + ((size_t)l * 5 + my_off) * total_q;
     const float* __restrict__ anc = anchors + (size_t)l * P.na * 2;
 
     // stage 1: (anchor, target) pairs that pass the ratio test, in anchor-major order (loss.py:191-194)
@@ -85,7 +103,7 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
         const int q = q0 + threadIdx.x;
         bool ok = false;
         if (q < total_q) {
-            const int a = q / P.nt, t = q - a * P.nt;
+            const int a = (int)dh_div((uint32_t)q, P.ntd), t = q - a * P.nt;
             const float gw = targets[(size_t)t * 6 + 4] * fnx, gh = targets[(size_t)t * 6 + 5] * fny;
             const float rw = __fdiv_rn(gw, anc[2 * a]), rh = __fdiv_rn(gh, anc[2 * a + 1]);
             const float worst = fmaxf(fmaxf(rw, __fdiv_rn(1.0f, rw)), fmaxf(rh, __fdiv_rn(1.0f, rh)));
@@ -128,12 +146,10 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
         oa[pos] = a;
         oj[pos] = gj;
         oi[pos] = gi;
-        obox[4 * pos + 0] = gx - (float)gi;
-        obox[4 * pos + 1] = gy - (float)gj;
-        obox[4 * pos + 2] = tr[4] * fnx;
-        obox[4 * pos + 3] = tr[5] * fny;
-        oanch[2 * pos + 0] = anc[2 * a];
-        oanch[2 * pos + 1] = anc[2 * a + 1];
+        // one 16-byte and one 8-byte store (the row stores of a level all leave from one compute unit: their number is
+        // what the kernel's duration is made of)
+        *reinterpret_cast<float4*>(obox + 4 * pos) = make_float4(gx - (float)gi, gy - (float)gj, tr[4] * fnx, tr[5] * fny);
+        *reinterpret_cast<float2*>(oanch + 2 * pos) = make_float2(anc[2 * a], anc[2 * a + 1]);
         ocls[pos] = (long long)tr[1];
     };
     if (n1 <= BT_CHUNKS * BT_THREADS) {
@@ -151,7 +167,7 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
             bits[ch] = 0; ra[ch] = 0; rt[ch] = 0; rgx[ch] = 0.f; rgy[ch] = 0.f;
             if (k < n1) {
                 const int q = list[k];
-                ra[ch] = q / P.nt; rt[ch] = q - ra[ch] * P.nt;
+                ra[ch] = (int)dh_div((uint32_t)q, P.ntd); rt[ch] = q - ra[ch] * P.nt;
                 rgx[ch] = targets[(size_t)rt[ch] * 6 + 2] * fnx;
                 rgy[ch] = targets[(size_t)rt[ch] * 6 + 3] * fny;
                 bits[ch] = offsets_taken(rgx[ch], rgy[ch]);
@@ -182,6 +198,7 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
         for (int ch = 0; ch < BT_CHUNKS; ++ch) {
 #pragma unroll
             for (int o = 0; o < 5; ++o) {
+                if (o != my_off) continue;
                 const bool take = (bits[ch] >> o) & 1u;
                 const unsigned long long m = __ballot(take);
                 if (take) {
@@ -201,19 +218,19 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
                 float gx = 0.f, gy = 0.f;
                 if (k < n1) {
                     const int q = list[k];
-                    a = q / P.nt; t = q - a * P.nt;
+                    a = (int)dh_div((uint32_t)q, P.ntd); t = q - a * P.nt;
                     gx = targets[(size_t)t * 6 + 2] * fnx;
                     gy = targets[(size_t)t * 6 + 3] * fny;
                     take = (offsets_taken(gx, gy) >> off) & 1u;
                 }
                 int tot;
                 const int rank = block_rank(take, tot, s_w, phase);
-                if (take) emit((size_t)n2 + rank, off, a, t, gx, gy);
+                if (take && off == my_off) emit((size_t)n2 + rank, off, a, t, gx, gy);
                 n2 += tot;
             }
         }
     }
-    if (threadIdx.x == 0) counts[l] = n2;
+    if (threadIdx.x == 0 && my_off == 0) counts[l] = n2;
 }
 
 }  // namespace
@@ -221,7 +238,7 @@ __global__ void __launch_bounds__(BT_THREADS) k_build_targets(const float* __res
 extern "C" size_t dh_build_targets_workspace(int nl, int na, int64_t nt)
 {
     if (nl <= 0 || na <= 0 || nt <= 0) return 256;
-    return (size_t)nl * na * nt * sizeof(int) + 256;
+    return (size_t)nl * 5 * na * nt * sizeof(int) + 256;      // the stage-1 list of every (level, offset) workgroup
 }
 
 // Shared by dh_build_targets and the fused loss entry: the assignment launch, which can also fill `fill_bytes`
@@ -239,6 +256,7 @@ int dh_launch_build_targets(const float* targets, int64_t nt, const float* ancho
         return dh_fill_async(counts, 0, sizeof(int) * nl, st);
     }
     if (!targets || !idx || !tbox || !anch || !tcls || !workspace || cap < 5ll * na * nt) return DH_ERR_ARG;
+    if (!dh_aligned16(tbox) || (reinterpret_cast<uintptr_t>(anch) & 7u)) return DH_ERR_ALIGN;     // rows are stored as vectors
     if (workspace_bytes < dh_build_targets_workspace(nl, na, nt)) return DH_ERR_WORKSPACE;
     bt_params P;
     for (int l = 0; l < nl; ++l) {
@@ -246,12 +264,12 @@ int dh_launch_build_targets(const float* targets, int64_t nt, const float* ancho
         P.ny[l] = ny[l];
         P.nx[l] = nx[l];
     }
-    P.nl = nl; P.na = na; P.nt = (int)nt; P.anchor_t = (float)anchor_t; P.cap = (long)cap;
+    P.nl = nl; P.na = na; P.nt = (int)nt; P.ntd = dh_make_fastdiv((uint32_t)nt); P.anchor_t = (float)anchor_t; P.cap = (long)cap;
     const size_t fill_vecs = fill_bytes / 16;
     // 32 KiB of fill per spare workgroup (two stores per thread), at most 512 of them
     size_t spare = (fill_vecs + 2 * BT_THREADS - 1) / (2 * BT_THREADS);
     if (spare > 512) spare = 512;
-    hipLaunchKernelGGL(k_build_targets, dim3(nl + (unsigned)spare), dim3(BT_THREADS), 0, st, targets, anchors, P, (int*)workspace,
+    hipLaunchKernelGGL(k_build_targets, dim3(5 * nl + (unsigned)spare), dim3(BT_THREADS), 0, st, targets, anchors, P, (int*)workspace,
                        (long long*)idx, tbox, anch, (long long*)tcls, counts, (uint4*)fill, fill_vecs);
     return dh_launch_status();
 }
