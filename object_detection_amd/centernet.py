@@ -59,19 +59,15 @@ def decode_bbox(pred_cls, pred_size, pred_offset, confidence, device=None):
 
 def centernet_correct_boxes(box_xy, box_wh, input_shape, image_shape, letterbox_image):
     """dataset.py:219-243.  numpy in, numpy out: the reference does this step on the host after .cpu()."""
-    input_shape = np.array(input_shape)
-    image_shape = np.array(image_shape)
-    if letterbox_image:
-        new_shape = np.round(image_shape * np.min(input_shape / image_shape))
-        offset = (input_shape - new_shape) / 2.0 / input_shape
-        scale = input_shape / new_shape
-        box_xy = (box_xy - offset) * scale
-        box_wh *= scale
-    box_mins = box_xy - (box_wh / 2.0)
-    box_maxes = box_xy + (box_wh / 2.0)
-    boxes = np.concatenate([box_mins[..., 0:1], box_mins[..., 1:2], box_maxes[..., 0:1], box_maxes[..., 1:2]], axis=-1)
-    boxes *= image_shape
-    return boxes
+    net, img = np.array(input_shape), np.array(image_shape)
+    if letterbox_image:      # undo the letterbox: the image sits centred in the network input, scaled to fit
+        fitted = np.round(img * np.min(net / img))
+        box_xy = (box_xy - (net - fitted) / 2.0 / net) * (net / fitted)
+        box_wh *= net / fitted                      # in place: the caller's array changes, as it does in the reference
+    half = box_wh / 2.0
+    corners = np.concatenate([(box_xy - half)[..., :2], (box_xy + half)[..., :2]], axis=-1)
+    corners *= img                                  # normalised -> pixels
+    return corners
 
 
 def _group_by_class(prediction, need_nms, nms_thres):
