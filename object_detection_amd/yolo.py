@@ -1,4 +1,5 @@
 """Drop-in for the YOLOv5 Detect head (object_detection/yolov5/models/yolo.py:33-81)."""
+import os
 import weakref
 
 import torch
@@ -8,6 +9,18 @@ from . import _lib as L
 
 
 _ANCHOR_CACHE = {}
+_USE_PLANES = os.environ.get("DH_COMPACT_PLANES", "1") != "0"
+
+
+def use_compact_planes(enabled):
+    """Switch for the compact objectness planes (also the environment variable DH_COMPACT_PLANES=0 at import).  Off:
+    NMS and the loss always read column 4 of the tensor they are given, whatever the decode left behind.  For callers that
+    write to decoded tensors or maps through channels the version counter does not see (`tensor.data`, raw pointers handed
+    to other libraries).  Returns the previous setting."""
+    global _USE_PLANES
+    before, _USE_PLANES = _USE_PLANES, bool(enabled)
+    return before
+
 _OBJ_PLANES = {}    # data_ptr of a decoded tensor -> (weakref to it, its version counter, compact objectness (bs, A))
 _LOGIT_PLANES = {}  # data_ptr of the first raw map -> ([(weakref, version, shape) per map], raw objectness logits (bs, A))
 
@@ -18,7 +31,7 @@ def objectness_plane(pred):
     It is only returned while `pred` is the very tensor detect_decode produced and has not been written to
     since (same storage, shape and version counter), so consumers may read it instead of the strided column.
     """
-    hit = _OBJ_PLANES.get(pred.data_ptr())
+    hit = _OBJ_PLANES.get(pred.data_ptr()) if _USE_PLANES else None
     if hit is None:
         return None
     ref, version, plane, made_on, in_capture = hit
@@ -51,7 +64,7 @@ def objectness_logits(maps):
     Valid only while every map still is the storage detect_decode read (the tensor it saw is alive, same
     address, shape and version counter, i.e. no in-place write since), so reading it is reading the maps.
     """
-    if not maps:
+    if not maps or not _USE_PLANES:
         return None
     hit = _LOGIT_PLANES.get(maps[0].data_ptr())
     if hit is None or len(hit[0]) != len(maps) or _stale_for_capture(hit[3]):

@@ -214,6 +214,14 @@ def test_nms_uses_decode_objectness_plane_only_while_valid():
     without = non_max_suppression(z.clone(), 0.25, 0.45)
     same_lists(with_plane, [w.cpu() for w in without])
     assert sum(w.shape[0] for w in without) > 100
+    from object_detection_amd.yolo import use_compact_planes
+    was = use_compact_planes(False)                     # the switch: the plane is there but nobody is handed it
+    try:
+        assert objectness_plane(z) is None
+        same_lists(non_max_suppression(z, 0.25, 0.45), [w.cpu() for w in without])
+    finally:
+        use_compact_planes(was)
+    assert objectness_plane(z) is not None
     z[:, :, 4] *= 0.5                                   # in-place edit: the side copy is stale now
     assert objectness_plane(z) is None
     same_lists(non_max_suppression(z, 0.25, 0.45), [w.cpu() for w in non_max_suppression(z.clone(), 0.25, 0.45)])
