@@ -194,6 +194,10 @@ def main():
     ap.add_argument("--autograd", action="store_true",
                     help="call loss = crit(p, t); autograd.grad(loss, p) instead of crit.forward_backward(p, t): same kernels, "
                          "plus the autograd engine's hop to its device thread and back (two thread wake-ups per step)")
+    ap.add_argument("--pre-roll", type=int, default=2000,
+                    help="untimed steps before the --warmup steps (reported as `pre_roll_steps`): a GPU that has idled through "
+                         "process start-up and the CPU baseline needs a few hundred milliseconds of work before its clocks and "
+                         "the allocator's pools are in the state a running loop sees; 0 disables")
     ap.add_argument("--post-roll", type=float, default=2.0,
                     help="seconds of the same steps after the timed region, reported as `sustained` (keeps the GPU busy "
                          "long enough for an outside monitor to see the run; 0 disables)")
@@ -413,8 +417,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup, False)
-    # timing events are created (and recorded once, which is what allocates them) outside the timed region
+    # Everything the timed region needs from the host is prepared BEFORE the warm-up, so that nothing but the barrier and the
+    # synchronisation the contract asks for sits between the last warm-up step and the first timed one: a GPU left idle for
+    # the tens of milliseconds that creating the events and a garbage collection take drops its clocks, and a short timed
+    # region (20 steps are 7 ms) would then be measured on the ramp back up (decode launches of 0.24 ms instead of 0.19 ms).
+    # Timing events are created here (and recorded once, which is what allocates them).
     mark_pool = [[torch.cuda.Event(enable_timing=True) for _ in range(7)] for _ in range(args.steps)]
     for marks in mark_pool:
         for m in marks:
@@ -423,6 +430,9 @@ def main():
     gc.collect()
     if not os.environ.get("DH_BENCH_KEEP_GC"):
         gc.disable()      # a serving loop does not want a cyclic-GC pause in the middle of a step
+    if args.pre_roll > 0:
+        run(args.pre_roll, False)
+    run(args.warmup, False)
     sync_all()
     t0 = time.perf_counter()
     all_marks, dets = run(args.steps, True)
@@ -531,6 +541,7 @@ def main():
             "collective": ("one all_reduce(SUM) of [lbox, lobj, lcls, n_pos] per step over RCCL on the side stream; step i's "
                            "vector travels while step i+1 is enqueued, the last step's inside the timed region") if dist_on else None,
             "collective_check": collective_check,
+            "pre_roll_steps": args.pre_roll,
             "sustained": sustained,
             "loss_call": "crit(p,t) + torch.autograd.grad" if args.autograd else (
                 "crit.positives(p,t) on a side stream beside the decode, then crit.forward_backward(p,t,positives=...)" if early
