@@ -169,6 +169,7 @@ __device__ __forceinline__ void wave_sync()
 #define DENSE_ROWS 16        // rows per LDS tile of the dense single-label path
 #define DENSE_REGS 24        // 64 * DENSE_REGS >= DENSE_ROWS * no, i.e. no <= 96
 #define DENSE_MIN 24         // candidates among a wave's 64 rows from which the dense path is taken
+#define DENSE_VREGS (DENSE_REGS / 4)   // 16-byte vectors per lane and tile on the vector form of that path
 
 // NCH > 0: the class scores of the rows in flight are fetched up front as NCH chunks of 64 classes
 // (nc <= 64*NCH), which keeps 4*NCH independent loads in flight per wave; NCH = 0 handles any nc
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
     const float* __restrict__ img = RAW ? nullptr : S.pred + (size_t)b * A * no;
     u64* __restrict__ out = keys + (size_t)b * cap_pad;
     __shared__ u64 stage[4][STAGE_KEYS];
-    extern __shared__ float s_dense[];        // single-label, dense != 0: 4 waves x DENSE_ROWS rows x no floats
+    extern __shared__ __align__(16) float s_dense[];   // single-label, dense != 0: 4 waves x DENSE_ROWS rows x no floats
     int pending = 0;
 
     // single label: the workgroup gathers its keys in LDS (all of `stage`) and takes room in the image's key list with one
@@ -215,8 +216,54 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
         if (!MULTI && dense && __popcll(todo) >= DENSE_MIN &&
             (!RAW || raw_row_of<T>(S, b, row0).l == raw_row_of<T>(S, b, min(row0 + 63, A - 1)).l)) {
             float* __restrict__ tile = s_dense + wave * (DENSE_ROWS * no);
+            // dense == 2 (decoded fp32 tensor, 16-byte aligned, A * no % 4 == 0): the full tiles of the wave's 64 rows come in
+            // as 16-byte vectors, DENSE_ROWS * no / 4 of them per tile, and the next tile's loads are issued -- unconditionally,
+            // so that waiting for this tile's vectors does not mean waiting for those -- before this tile is looked at.
+            int sub_first = 0;
+            if (!RAW && sizeof(T) == 4 && dense == 2) {
+                const int full = min(64 / DENSE_ROWS, (A - row0) / DENSE_ROWS);     // wave-uniform
+                const int nv = DENSE_ROWS / 4 * no;                                  // vectors per tile
+                const dh_f4* __restrict__ rows4 = reinterpret_cast<const dh_f4*>(img + (size_t)row0 * no);
+                dh_f4 buf[2][DENSE_VREGS];
+                if (full > 0) {
+#pragma unroll
+                    for (int i = 0; i < DENSE_VREGS; ++i) buf[0][i] = rows4[min(i * 64 + lane, nv - 1)];
+                }
+#pragma unroll
+                for (int sub = 0; sub < 64 / DENSE_ROWS; ++sub) {
+                    if (sub >= full) break;
+                    const int nx = sub + 1 < full ? sub + 1 : sub;                   // no next tile: its own once more
+#pragma unroll
+                    for (int i = 0; i < DENSE_VREGS; ++i) buf[(sub + 1) & 1][i] = rows4[(size_t)nx * nv + min(i * 64 + lane, nv - 1)];
+#pragma unroll
+                    for (int i = 0; i < DENSE_VREGS; ++i)
+                        if (i * 64 + lane < nv) reinterpret_cast<dh_f4*>(tile)[i * 64 + lane] = buf[sub & 1][i];
+                    wave_sync();
+                    const int rr = lane >> 2, part = lane & 3;
+                    const float myo = __shfl(obj, DENSE_ROWS * sub + rr, 64);
+                    float qv = -INFINITY;
+                    int qc = 0x7fffffff;
+                    const float* __restrict__ rowp = tile + rr * no + 5;
+#pragma unroll 4
+                    for (int c = part; c < nc; c += 4) {
+                        const float sc = rowp[c] * myo;                                         // general.py:691
+                        if (sc > qv) { qv = sc; qc = c; }
+                    }
+#pragma unroll
+                    for (int d = 2; d > 0; d >>= 1) {
+                        const float ov = __shfl_xor(qv, d, 64);
+                        const int oc = __shfl_xor(qc, d, 64);
+                        if (ov > qv || (ov == qv && oc < qc)) { qv = ov; qc = oc; }
+                    }
+                    const float rv = __shfl(qv, 4 * (lane & (DENSE_ROWS - 1)), 64);             // general.py:701 (first max)
+                    const int rc = __shfl(qc, 4 * (lane & (DENSE_ROWS - 1)), 64);
+                    if ((lane / DENSE_ROWS) == sub) { my_best = rv; my_cls = rc; }
+                    wave_sync();
+                }
+                sub_first = full > 0 ? full : 0;
+            }
 #pragma unroll 1
-            for (int sub = 0; sub < 64 / DENSE_ROWS; ++sub) {
+            for (int sub = sub_first; sub < 64 / DENSE_ROWS; ++sub) {
                 const int rs = row0 + DENSE_ROWS * sub;
                 if (rs >= A) break;
                 if (((todo >> (DENSE_ROWS * sub)) & ((1ull << DENSE_ROWS) - 1ull)) == 0) continue;
@@ -2294,11 +2341,15 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
             streamed = true;
         }
     }
-    int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks
+    int gx = (A + 255) / 256;                       // one 64-row group per wave, unless that makes > 8192 blocks:
     const int gx_cap = 8192 / bs > 1 ? 8192 / bs : 1;
-    if (gx > gx_cap) gx = gx_cap;
+    if (gx > gx_cap) {                              // then every workgroup takes the same number of groups (one fewer for the
+        const int rounds = (gx + gx_cap - 1) / gx_cap;      // last few), instead of some taking two and the rest one
+        gx = (gx + rounds - 1) / rounds;
+    }
     // dense single-label path: 4 waves x DENSE_ROWS rows x no floats of LDS, when a tile fits the per-lane registers
-    const int dense = (!multi_label && nc + 5 <= 64 * DENSE_REGS / DENSE_ROWS) ? 1 : 0;
+    int dense = (!multi_label && nc + 5 <= 64 * DENSE_REGS / DENSE_ROWS) ? 1 : 0;
+    if (dense && !raw && dh_aligned16(S.pred) && ((long long)A * (nc + 5)) % 4 == 0) dense = 2;      // tiles as 16-byte vectors
     const size_t dense_lds = dense ? sizeof(float) * 4 * DENSE_ROWS * (nc + 5) : 0;
 #define DH_PREFILTER(M, N, R, T) hipLaunchKernelGGL((k_nms_prefilter<M, N, R, T>), dim3(gx, bs), dim3(256), (M) ? 0 : dense_lds, st, S, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts, dense)
 #define DH_PREFILTER_N(M, R, T) do { if (nc <= 64) DH_PREFILTER(M, 1, R, T); else if (nc <= 128) DH_PREFILTER(M, 2, R, T); else DH_PREFILTER(M, 0, R, T); } while (0)
