@@ -127,6 +127,33 @@ def test_nms_dense_stress_vs_oracle():
         same_lists(got, want)
 
 
+@pytest.mark.parametrize("A,nc", [(15, 3), (16, 80), (17, 80), (63, 7), (64, 1), (65, 80), (1000, 80), (1023, 2), (4097, 80),
+                                  (4112, 91), (777, 92), (2048, 11)])
+def test_nms_dense_single_label_shapes_vs_oracle(A, nc):
+    """Single-label candidate search when most rows are candidates, over row counts and widths that take every form of
+    the tile path: 16-row tiles as 16-byte vectors (A * no % 4 == 0), the scalar tiles (otherwise, and for the last
+    rows of an image when A % 16 != 0), rows too wide for a tile (no > 96: candidate rows four at a time), and a prediction
+    tensor that does not start on a 16-byte boundary."""
+    from object_detection_amd.general import non_max_suppression
+    rs = np.random.RandomState(1000 + A + nc)
+    bs = 3
+    pred = np.zeros((bs, A, 5 + nc), dtype=np.float32)
+    pred[..., 0:2] = rs.uniform(0, 640, (bs, A, 2))
+    pred[..., 2:4] = np.exp(rs.uniform(np.log(4), np.log(64), (bs, A, 2)))
+    pred[..., 4] = rs.uniform(0.2, 1, (bs, A))                      # ~7 of 8 rows pass conf 0.3
+    logits = rs.normal(0, 3, (bs, A, nc))
+    pred[..., 5:] = np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)
+    pred[1, : A // 2, 4] = 0.0                                      # an image whose first half has no candidate at all
+    kw = dict(conf_thres=0.3, iou_thres=0.5, max_det=1000)
+    want = onms.non_max_suppression(T(pred).clone(), **kw)
+    same_lists(non_max_suppression(T(pred).cuda(), **kw), want)
+    shifted = torch.empty(pred.size + 1, device="cuda")[1:].view(pred.shape)      # 4 bytes past a 16-byte boundary
+    shifted.copy_(T(pred))
+    assert shifted.data_ptr() % 16 == 4 and shifted.is_contiguous()
+    same_lists(non_max_suppression(shifted, **kw), want)
+    assert sum(w.shape[0] for w in want) > 0
+
+
 def test_nms_huge_boxes_cross_class_overlap():
     """Boxes wider than the 7680 px class offset overlap across classes in the reference; so must we."""
     from object_detection_amd.general import non_max_suppression
