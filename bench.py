@@ -374,14 +374,15 @@ def main():
                 host_s[s] += d
         return dict(marks=marks, z=z, rows=rows, host_meta=host_meta, copied=copied, loss=loss, grads=grads, stats=stats)
 
-    def finish(job):
+    def finish(job, record=False):
         """Host half of a step: wait for that step's copy only, then build the per-image detection views."""
         job["copied"].synchronize()
         h0 = time.perf_counter()
         dets, _ = nms_views(job["rows"], job["host_meta"].tolist(), cap)
         if dets is None:      # the fast first attempt was not enough for some image (never with this workload): blocking repeat
             dets = non_max_suppression(job["z"], 0.25, 0.45, max_det=300)
-        host_s["finish"] += time.perf_counter() - h0
+        if record:
+            host_s["finish"] += time.perf_counter() - h0
         return dets
 
     step_wall = []
@@ -396,7 +397,7 @@ def main():
                 step_wall.append(time.perf_counter())
             job = launch(record, i % SAMPLE_EVERY == 0)
             if prev is not None:
-                dets = finish(prev)      # prev's tensors are released here, so the allocator reuses its blocks
+                dets = finish(prev, record)      # prev's tensors are released here, so the allocator reuses its blocks
             prev = job
             all_marks.append((job["marks"], i % SAMPLE_EVERY == 0))
         if dist_on and overlap and split["prev_stats"] is not None:
@@ -409,7 +410,7 @@ def main():
             split["prev_stats"] = None
             set_stream(main_stream)
         if prev is not None:
-            dets = finish(prev)
+            dets = finish(prev, record)
         return all_marks, dets
 
     def sync_all():

@@ -4,8 +4,8 @@
   python tools/summarise_profile.py gpurun_out/prof r1      -> profiles/r1_bench_kernel_stats.csv, profiles/r1_pmc_traffic.json
 Expects <dir>/kt, <dir>/fetch, <dir>/write as written by
   rocprofv3 --kernel-trace --stats --output-format csv -d <dir>/kt    -- python3 bench.py --no-cpu-baseline
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir>/fetch       -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d <dir>/write       -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir>/fetch       -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --pre-roll 0 --post-roll 0
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d <dir>/write       -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --pre-roll 0 --post-roll 0
 """
 import collections
 import csv
@@ -50,7 +50,8 @@ for r in csv.DictReader(open(stats_out)):
         calls = avg_us.get(k, (0, 0.0))
         avg_us[k] = (calls[0] + int(r["Calls"]), calls[1] + float(r["TotalDurationNs"]))
 out = {
-    "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 ; the same with --pmc WRITE_SIZE "
+    "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 --pre-roll 0 --post-roll 0 ; the "
+               "same with --pmc WRITE_SIZE "
                "(separate passes); durations from rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline "
                f"(profiles/{tag}_bench_kernel_stats.csv)",
     "units": "FETCH_SIZE / WRITE_SIZE are reported in KiB. On gfx950 FETCH_SIZE counts a wide coalesced read request at half its "
