@@ -259,10 +259,13 @@ typedef struct dh_yolo_hyp {
  * p / grad_p: host arrays of nl device pointers to (bs,na,ny,nx,5+nc) maps.
  * out (device, 6+nl floats): [0] loss, [1..3] lbox, lobj, lcls after gains, [4] assigned rows over all
  * levels, [5..5+nl) mean objectness BCE per level (what autobalance reads, loss.py:158), [5+nl] rows
- * ignored because their image/anchor index was outside the maps.  The forward leaves in `workspace` what the backward needs (per-row IoU and
- * the cell-owner map), so the same workspace must be passed to dh_yolo_loss_bwd unmodified.
+ * ignored because their image/anchor index was outside the maps.  The forward leaves in `workspace` what the backward needs (per-row IoU,
+ * the per-cell lists of assigned rows, the stored objectness derivative), so the same workspace must be passed to
+ * dh_yolo_loss_bwd unmodified.
  * The backward writes every element of every grad_p[l] (no pre-zeroing needed); grad_loss is the
- * upstream gradient of out[0] (1 float, device).
+ * upstream gradient of out[0] (1 float, device).  The rows assigned to one cell are summed in row order by one wave and
+ * stored, so the gradient is the same bit for bit on every run (index_put(accumulate=True) applied sequentially, as the
+ * reference's backward does on the CPU); only a cell shared by more than 64 rows falls back to floating-point atomics.
  * obj_logits: NULL, or the (bs, sum_l na*ny*nx) plane dh_yolo_decode wrote for exactly these maps
  * (obj_logits[b][first_l + (a*ny+gj)*nx+gi] == p[l][b][a][gj][gi][4] bit for bit); the dense objectness
  * pass then reads it instead of the strided column. */
@@ -278,7 +281,7 @@ int dh_yolo_loss_bwd(const float* const* p, const int* ny, const int* nx, int nl
 
 /* dh_build_targets + dh_yolo_loss_fwd + dh_yolo_loss_bwd as one sequence of five launches (a training step's
  * `loss = compute_loss(pred, targets); loss.backward()`, object_detection/yolov5/train.py:329,337, when the caller
- * takes the gradients directly): the owner-map fill rides in spare workgroups of the assignment launch and the
+ * takes the gradients directly): the fill of the per-cell map rides in spare workgroups of the assignment launch and the
  * forward's final reduction in workgroup 0 of the dense gradient launch, so neither costs a launch of its own.
  * Arguments as in the three entries; idx/tbox/anch/tcls/counts are outputs (the assignment), assign_workspace is
  * dh_build_targets_workspace bytes, workspace dh_yolo_loss_workspace bytes.  out and grad_p as in the separate calls. */
@@ -310,8 +313,8 @@ int dh_yolo_loss_fwd_bwd_conv(const float* targets, int64_t nt, const float* anc
  * fp32, so the forward equals the fp32 entry on the outputs converted with .float().
  * grad_f16 == 0: grad_conv[l] are fp32 tensors and equal the fp32 entry's gradient.
  * grad_f16 != 0: grad_conv[l] are fp16 tensors, the type autograd hands back to an fp16 convolution: an element that
- * receives one term is that term rounded to fp16; a cell assigned to several target rows accumulates their terms with the
- * hardware's packed fp16 atomic add (one rounding per term). */
+ * receives one term is that term rounded to fp16; a cell assigned to several target rows gets the fp32 sum of their terms
+ * (in row order) rounded once -- beyond 64 rows on one cell, the hardware's packed fp16 atomic add, one rounding per term. */
 int dh_yolo_loss_fwd_conv_f16(const void* const* conv, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                               const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
                               int64_t cap, const dh_yolo_hyp* hyp, float* out, void* workspace, size_t workspace_bytes,

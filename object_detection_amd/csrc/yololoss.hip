@@ -8,11 +8,15 @@
 //   loss = (lbox*box + lobj*obj + lcls*cls) * bs
 //
 // Forward = 3 launches: positives (one wave per assigned row), dense objectness (reads the strided
-// obj logit of every anchor + a 4-byte owner word), finalisation.  The dense tobj tensor is never
-// built: a per-cell owner map (last assigned row, by atomicMax of the row id) stands in for it.
-// The objectness pass also stores d BCE / d logit per anchor (4 B each), so the backward never re-reads
-// the strided logits.  Backward = 2 launches: one streaming pass writes the whole dense gradient (zeros +
-// scaled objectness term, 16-byte stores), then the positive rows add their box / class terms.
+// obj logit of every anchor + a 4-byte word of the cell map), finalisation.  The dense tobj tensor is never
+// built: a per-cell map stands in for it.  Each assigned row exchanges its id into its cell's word and keeps
+// what it found there, so the rows of a cell form a list (usually of one); the cell's target comes from the
+// largest row id in it -- the reference's "last duplicate wins" (loss.py:143) -- whatever order the exchanges
+// happened in.  The objectness pass also stores d BCE / d logit per anchor (4 B each), so the backward never
+// re-reads the strided logits.  Backward = 2 launches: one streaming pass writes the whole dense gradient
+// (zeros + scaled objectness term, 16-byte stores), then, per cell with assigned rows, the cell's last row sums
+// the box / class terms of all of them in row order and stores the sums: the gradient is the same bit for bit
+// on every run, and the order is that of a sequential index_put(accumulate=True).
 //
 // Convolution layout (the *_conv entries): the maps are the outputs of the head's 1x1 convolutions as they are,
 // (bs, na*no, ny, nx), i.e. what Detect.forward holds before the permuted copy of object_detection/yolov5/models/yolo.py:54,
@@ -147,7 +151,7 @@ template <bool CONV, typename T = float>
 __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
                                                     const long long* __restrict__ tcls, const int* __restrict__ counts,
-                                                    int* __restrict__ owner, float* __restrict__ iou_ws,
+                                                    int* __restrict__ owner, int* __restrict__ nxt, float* __restrict__ iou_ws,
                                                     float* __restrict__ cls_ws, int* __restrict__ invalid)
 {
     const int l = blockIdx.y;
@@ -180,7 +184,8 @@ __global__ void __launch_bounds__(256) k_yl_pos_fwd(const yl_params P, const lon
     if (lane == 0) {
         iou_out[r] = iou;
         cls_out[r] = csum;
-        atomicMax(owner + L.cell_first + R.cell, (int)r);      // last assigned row owns the cell (loss.py:143)
+        // the row joins its cell's list: the cell's word names the row that arrived last, every row the one before it
+        nxt[(size_t)l * P.cap + r] = atomicExch(owner + L.cell_first + R.cell, (int)r);
     }
 }
 
@@ -194,10 +199,24 @@ __device__ __forceinline__ int level_of_block(const yl_params& P, unsigned& blk)
     return l;
 }
 
-__device__ __forceinline__ float tobj_of(const yl_params& P, int own, const float* __restrict__ iou_l)
+// The largest row id in the list that starts at `head` (-1: none): the row whose value index_put_ leaves in the cell
+// (loss.py:143).  The walk is bounded by the row capacity, whatever the words hold.
+__device__ __forceinline__ int last_row_of(int head, const int* __restrict__ nxt_l, long cap)
 {
-    if (own < 0) return 0.0f;
-    return (1.0f - P.gr) + P.gr * fmaxf(iou_l[own], 0.0f);                                       // loss.py:139,143
+    int m = head;
+    long steps = 0;
+    for (int j = head; j >= 0 && steps < cap; ++steps) {
+        m = j > m ? j : m;
+        j = nxt_l[j];
+    }
+    return m;
+}
+
+__device__ __forceinline__ float tobj_of(const yl_params& P, int head, const float* __restrict__ iou_l,
+                                         const int* __restrict__ nxt_l)
+{
+    if (head < 0) return 0.0f;
+    return (1.0f - P.gr) + P.gr * fmaxf(iou_l[last_row_of(head, nxt_l, P.cap)], 0.0f);           // loss.py:139,143
 }
 
 #define OBJ_CELLS_PER_BLOCK 1024
@@ -206,13 +225,15 @@ __device__ __forceinline__ float tobj_of(const yl_params& P, int own, const floa
 // moves the compact logits, the owner words and the stored derivative as 16-byte vectors.
 template <bool VEC, bool CONV = false, typename T = float>
 __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int* __restrict__ owner,
-                                                    const float* __restrict__ iou_ws, double* __restrict__ partial,
-                                                    float* __restrict__ dobj, const float* __restrict__ logits)
+                                                    const int* __restrict__ nxt, const float* __restrict__ iou_ws,
+                                                    double* __restrict__ partial, float* __restrict__ dobj,
+                                                    const float* __restrict__ logits)
 {
     unsigned blk = blockIdx.x;
     const int l = level_of_block(P, blk);
     const yl_level& L = P.lvl[l];
     const float* __restrict__ iou_l = iou_ws + (size_t)l * P.cap;
+    const int* __restrict__ nxt_l = nxt + (size_t)l * P.cap;
     const int* __restrict__ own_l = owner + L.cell_first;
     double acc = 0.0;
     if (VEC) {
@@ -227,7 +248,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
             float d[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float t = tobj_of(P, o[k], iou_l);
+                const float t = tobj_of(P, o[k], iou_l, nxt_l);
                 acc += (double)bce_value(x[k], t, P.obj_pw, P.gamma);                              // loss.py:155
                 d[k] = bce_grad(x[k], t, P.obj_pw, P.gamma);
             }
@@ -251,7 +272,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int
                     // and keeps it out of the caches (measured 2.2x faster than a default load on a cold tensor)
                     x = __builtin_nontemporal_load(L.p + (size_t)cell * P.no + 4);
                 }
-                const float t = tobj_of(P, own_l[cell], iou_l);
+                const float t = tobj_of(P, own_l[cell], iou_l, nxt_l);
                 acc += (double)bce_value(x, t, P.obj_pw, P.gamma);                                 // loss.py:155
                 // the backward needs d BCE / d logit of every anchor: keep it compact (4 B per anchor) so that
                 // the gradient pass does not have to touch the 340-byte-strided logits again
@@ -428,11 +449,46 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, cons
 }
 
 // ------------------------------------------------------------------------------------ backward: positives
+// One wave per assigned row.  The rows of a cell (its list, see k_yl_pos_fwd) are handled by the cell's last row alone:
+// lane i of that wave takes the list's i-th row, the rows are ranked by id, and their box / class terms are summed in
+// ascending row order -- what a sequential index_put(accumulate=True) over the rows would add up -- and stored (the dense
+// pass has zero-filled these elements; nobody else writes them).  The other rows of the cell have nothing to do.
+// A cell shared by more than POS_MATES rows (hundreds of targets on one grid cell and anchor) falls back to one
+// floating-point atomic per row and element, whose order is not fixed.
+#define POS_MATES 64
+
+template <typename G> __device__ __forceinline__ void put_el(float* base, size_t k, float v, bool atomic);
+template <> __device__ __forceinline__ void put_el<float>(float* base, size_t k, float v, bool atomic)
+{
+    if (atomic) atomicAdd(base + k, v); else base[k] = v;
+}
+template <> __device__ __forceinline__ void put_el<_Float16>(float* base, size_t k, float v, bool atomic)
+{
+    if (atomic) add_el<_Float16>(base, k, v); else reinterpret_cast<_Float16*>(base)[k] = (_Float16)v;
+}
+
+// d loss / d logit of box channel `lane` (0..3) from one row: target box b, anchor (a0, a1); s = sigmoid of the four logits
+__device__ __forceinline__ float box_term(int lane, float s0, float s1, float s2, float s3, float a0, float a1, float b0, float b1,
+                                          float b2, float b3, float g_iou)
+{
+    const float tw = s2 * 2.0f, th = s3 * 2.0f;
+    const dh_corners a = dh_from_xywh(s0 * 2.0f - 0.5f, s1 * 2.0f - 0.5f, (tw * tw) * a0, (th * th) * a1);
+    dh_corners gc;
+    dh_iou_value_grad<DH_CIOU>(a, dh_from_xywh(b0, b1, b2, b3), 1e-7f, (float)(1.0 + 1e-7), g_iou, gc);
+    float gx, gy, gw, gh;
+    dh_grad_to_xywh(gc, gx, gy, gw, gh);
+    if (lane == 0) return gx * 2.0f * s0 * (1.0f - s0);
+    if (lane == 1) return gy * 2.0f * s1 * (1.0f - s1);
+    if (lane == 2) return gw * (2.0f * tw * a0) * (2.0f * s2 * (1.0f - s2));
+    return gh * (2.0f * th * a1) * (2.0f * s3 * (1.0f - s3));
+}
+
 template <bool CONV, typename T = float, typename G = float>
 __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
                                                     const long long* __restrict__ tcls, const int* __restrict__ counts,
-                                                    const float* __restrict__ g_loss)
+                                                    const float* __restrict__ g_loss, const int* __restrict__ owner,
+                                                    const int* __restrict__ nxt)
 {
     const int l = blockIdx.y;
     const yl_level& L = P.lvl[l];
@@ -444,37 +500,88 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
     if (!R.ok) return;
     const float* __restrict__ ps = L.p + (sizeof(T) == 4 ? R.off : 0);
     const size_t e0 = sizeof(T) == 4 ? 0 : R.off;
-    float* __restrict__ gs = L.g + (sizeof(G) == 4 ? R.off : 0);      // fp16 gradient: add_el applies element offsets
+    float* __restrict__ gs = L.g + (sizeof(G) == 4 ? R.off : 0);      // fp16 gradient: put_el applies element offsets
     const size_t g0 = sizeof(G) == 4 ? 0 : R.off;
     const size_t cs = CONV ? R.cs : 1;
+    // The cell's logits do not depend on the list, and neither does this row's own link: all these loads go out together,
+    // so the usual case -- the row is alone on its cell -- costs no round trip more than reading the row itself.
+    const float x0 = ld_el<T>(ps, e0), x1 = ld_el<T>(ps, e0 + cs), x2 = ld_el<T>(ps, e0 + 2 * cs), x3 = ld_el<T>(ps, e0 + 3 * cs);
+    const float xc0 = lane < P.nc ? ld_el<T>(ps, e0 + (5 + lane) * cs) : 0.0f;
+    const float xc1 = lane + 64 < P.nc ? ld_el<T>(ps, e0 + (5 + lane + 64) * cs) : 0.0f;
+    const int* __restrict__ nxt_l = nxt + (size_t)l * P.cap;
+    const int head = owner[L.cell_first + R.cell];
+    const int before_me = nxt_l[r];
+
     const float up = g_loss[0] * (float)P.bs;
-    if (lane < 4) {
-        const float x0 = ld_el<T>(ps, e0), x1 = ld_el<T>(ps, e0 + cs), x2 = ld_el<T>(ps, e0 + 2 * cs), x3 = ld_el<T>(ps, e0 + 3 * cs);
-        const float s0 = dh_sigmoid(x0), s1 = dh_sigmoid(x1), s2 = dh_sigmoid(x2), s3 = dh_sigmoid(x3);
-        const float tw = s2 * 2.0f, th = s3 * 2.0f;
-        const dh_corners a = dh_from_xywh(s0 * 2.0f - 0.5f, s1 * 2.0f - 0.5f, (tw * tw) * R.an[0], (th * th) * R.an[1]);
-        dh_corners gc;
-        // d lbox / d iou = -box/n  (lbox += mean(1 - iou))
-        dh_iou_value_grad<DH_CIOU>(a, dh_from_xywh(R.tb[0], R.tb[1], R.tb[2], R.tb[3]), 1e-7f, (float)(1.0 + 1e-7),
-                                   -up * P.box / (float)n, gc);
-        float gx, gy, gw, gh;
-        dh_grad_to_xywh(gc, gx, gy, gw, gh);
-        float g;
-        if (lane == 0) g = gx * 2.0f * s0 * (1.0f - s0);
-        else if (lane == 1) g = gy * 2.0f * s1 * (1.0f - s1);
-        else if (lane == 2) g = gw * (2.0f * tw * R.an[0]) * (2.0f * s2 * (1.0f - s2));
-        else g = gh * (2.0f * th * R.an[1]) * (2.0f * s3 * (1.0f - s3));
-        add_el<G>(gs, g0 + lane * cs, g);   // duplicates of one cell accumulate, as index_put(accumulate) does
+    const float s0 = dh_sigmoid(x0), s1 = dh_sigmoid(x1), s2 = dh_sigmoid(x2), s3 = dh_sigmoid(x3);
+    const float g_iou = -up * P.box / (float)n;                  // d lbox / d iou = -box/n  (lbox += mean(1 - iou))
+    const float sc = up * P.cls / ((float)n * (float)P.nc);
+    if (head == (int)r && before_me < 0) {
+        // alone on its cell: the row's own terms, stored
+        if (lane < 4)
+            put_el<G>(gs, g0 + lane * cs, box_term(lane, s0, s1, s2, s3, R.an[0], R.an[1], R.tb[0], R.tb[1], R.tb[2], R.tb[3], g_iou), false);
+        if (P.nc > 1) {
+            for (int c0 = 0; c0 < P.nc; c0 += 64) {
+                const int c = c0 + lane;
+                const float x = c0 == 0 ? xc0 : (c0 == 64 ? xc1 : (c < P.nc ? ld_el<T>(ps, e0 + (5 + c) * cs) : 0.0f));
+                if (c < P.nc) put_el<G>(gs, g0 + (5 + c) * cs, sc * bce_grad(x, c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma), false);
+            }
+        }
+        return;
     }
+    // the cell's rows: lane i keeps the i-th of the list; `last` is the largest id, `k` their number
+    int k = 0, last = -1, mine = -1;
+    for (int j = head; j >= 0 && k <= (int)P.cap; j = nxt_l[j]) {
+        if (lane == k) mine = j;
+        last = j > last ? j : last;
+        ++k;
+    }
+    const bool shared = k <= POS_MATES;
+    if (shared && last != (int)r) return;                     // wave-uniform: this row is not the cell's last
+    if (!shared) { k = 1; mine = lane == 0 ? (int)r : -1; }   // too many rows for one wave: every row adds its own terms
+
+    // lane i < k: target box, anchor and class of its row
+    float tb0 = 0.f, tb1 = 0.f, tb2 = 0.f, tb3 = 0.f, an0 = 0.f, an1 = 0.f;
+    int mcls = 0;
+    if (lane < k) {
+        if (mine == (int)r) {
+            tb0 = R.tb[0]; tb1 = R.tb[1]; tb2 = R.tb[2]; tb3 = R.tb[3]; an0 = R.an[0]; an1 = R.an[1]; mcls = R.cls;
+        } else {
+            const float4 tb = *reinterpret_cast<const float4*>(tbox + ((size_t)l * P.cap + mine) * 4);
+            const float2 an = *reinterpret_cast<const float2*>(anch + ((size_t)l * P.cap + mine) * 2);
+            tb0 = tb.x; tb1 = tb.y; tb2 = tb.z; tb3 = tb.w; an0 = an.x; an1 = an.y;
+            mcls = (int)tcls[(size_t)l * P.cap + mine];
+        }
+    }
+    // order[t] (held by lane t): the lane whose row has the t-th smallest id
+    int rank = 0, order = 0;
+    for (int t = 0; t < k; ++t) rank += __shfl(mine, t, 64) < mine ? 1 : 0;
+    for (int t = 0; t < k; ++t) order = __shfl(rank, t, 64) == lane ? t : order;
+
+    float gbox = 0.0f;
+    for (int t = 0; t < k; ++t) {
+        const int src = __shfl(order, t, 64);
+        const float b0 = __shfl(tb0, src, 64), b1 = __shfl(tb1, src, 64), b2 = __shfl(tb2, src, 64), b3 = __shfl(tb3, src, 64);
+        const float a0 = __shfl(an0, src, 64), a1 = __shfl(an1, src, 64);
+        if (lane < 4) gbox += box_term(lane, s0, s1, s2, s3, a0, a1, b0, b1, b2, b3, g_iou);      // in row order, like index_put(accumulate)
+    }
+    if (lane < 4) put_el<G>(gs, g0 + lane * cs, gbox, !shared);
     if (P.nc > 1) {
-        const float sc = up * P.cls / ((float)n * (float)P.nc);
-        for (int c = lane; c < P.nc; c += 64)
-            add_el<G>(gs, g0 + (5 + c) * cs, sc * bce_grad(ld_el<T>(ps, e0 + (5 + c) * cs), c == R.cls ? P.cp : P.cn, P.cls_pw, P.gamma));
+        for (int c0 = 0; c0 < P.nc; c0 += 64) {
+            const int c = c0 + lane;
+            const float x = c0 == 0 ? xc0 : (c0 == 64 ? xc1 : (c < P.nc ? ld_el<T>(ps, e0 + (5 + c) * cs) : 0.0f));
+            float acc = 0.0f;
+            for (int t = 0; t < k; ++t) {
+                const int cls_t = __shfl(mcls, __shfl(order, t, 64), 64);
+                acc += sc * bce_grad(x, c == cls_t ? P.cp : P.cn, P.cls_pw, P.gamma);
+            }
+            if (c < P.nc) put_el<G>(gs, g0 + (5 + c) * cs, acc, !shared);
+        }
     }
 }
 
 struct yl_ws {
-    size_t off_owner, off_iou, off_cls, off_partial, off_invalid, off_dobj, total;
+    size_t off_owner, off_iou, off_cls, off_partial, off_invalid, off_dobj, off_next, total;
     long cells_total;
     unsigned obj_blocks;
 };
@@ -534,6 +641,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
     W.off_cls = o; o = up256(o + sizeof(float) * (size_t)nl * (cap > 0 ? cap : 1));
     W.off_partial = o; o = up256(o + sizeof(double) * fwd_blocks);
     W.off_dobj = o; o = up256(o + sizeof(float) * (size_t)first);
+    W.off_next = o; o = up256(o + sizeof(int) * (size_t)nl * (cap > 0 ? cap : 1));      // per row: the row before it in its cell's list
     W.off_invalid = W.off_owner + sizeof(int) * (size_t)first;
     W.total = o;
     (void)blocks;
@@ -571,29 +679,30 @@ int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx,
     float* cls_ws = (float*)(ws + W.off_cls);
     double* partial = (double*)(ws + W.off_partial);
     int* invalid = (int*)(ws + W.off_invalid);
+    int* nxt = (int*)(ws + W.off_next);
     // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
     // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
     if (fill && dh_fill_async(owner, 0xFF, W.off_iou - W.off_owner, st) != DH_OK) return DH_ERR_LAUNCH;
     if (P.cap > 0 && (parts & 1)) {
         if (P.conv && P.half) hipLaunchKernelGGL((k_yl_pos_fwd<true, _Float16>), dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
-                                                 (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+                                                 (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, nxt, iou_ws, cls_ws, invalid);
         else if (P.conv) hipLaunchKernelGGL(k_yl_pos_fwd<true>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
-                                       (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+                                       (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, nxt, iou_ws, cls_ws, invalid);
         else hipLaunchKernelGGL(k_yl_pos_fwd<false>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
-                                (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, iou_ws, cls_ws, invalid);
+                                (const long long*)idx, tbox, anch, (const long long*)tcls, counts, owner, nxt, iou_ws, cls_ws, invalid);
     }
     if (!(parts & 2)) return dh_launch_status();
     // 16-byte vectors when the compact logits are there and every level keeps four consecutive cells inside one image
     bool vec = obj_logits != nullptr && dh_aligned16(obj_logits) && P.rows_per_image % 4 == 0;
     for (int l = 0; l < P.nl; ++l)
         vec = vec && P.lvl[l].per_image.d % 4 == 0 && P.lvl[l].row_first % 4 == 0 && P.lvl[l].cell_first % 4 == 0;
-    if (P.conv && P.half) hipLaunchKernelGGL((k_yl_obj_fwd<false, true, _Float16>), dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws,
+    if (P.conv && P.half) hipLaunchKernelGGL((k_yl_obj_fwd<false, true, _Float16>), dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, nxt, iou_ws,
                                              partial, (float*)(ws + W.off_dobj), obj_logits);
-    else if (P.conv) hipLaunchKernelGGL((k_yl_obj_fwd<false, true>), dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
+    else if (P.conv) hipLaunchKernelGGL((k_yl_obj_fwd<false, true>), dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, nxt, iou_ws, partial,
                                    (float*)(ws + W.off_dobj), obj_logits);
-    else if (vec) hipLaunchKernelGGL(k_yl_obj_fwd<true>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
+    else if (vec) hipLaunchKernelGGL(k_yl_obj_fwd<true>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, nxt, iou_ws, partial,
                                 (float*)(ws + W.off_dobj), obj_logits);
-    else hipLaunchKernelGGL(k_yl_obj_fwd<false>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, iou_ws, partial,
+    else hipLaunchKernelGGL(k_yl_obj_fwd<false>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, nxt, iou_ws, partial,
                             (float*)(ws + W.off_dobj), obj_logits);
     if (final)
         hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(FINAL_THREADS), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
@@ -605,6 +714,8 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
                const int64_t* tcls, const int* counts, const float* grad_loss, float* const* grad_p, const yl_final_args* F,
                hipStream_t st)
 {
+    const int* owner = (const int*)(ws + W.off_owner);
+    const int* nxt = (const int*)(ws + W.off_next);
     if (P.conv) {
         bool v4 = true;
         for (int l = 0; l < P.nl; ++l) v4 = v4 && P.lvl[l].plane.d % 4 == 0 && dh_aligned16(grad_p[l]);
@@ -628,7 +739,7 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
             }
             if (P.cap > 0)
                 hipLaunchKernelGGL((k_yl_pos_bwd<true, _Float16, _Float16>), dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
-                                   (const long long*)idx, tbox, anch, (const long long*)tcls, counts, grad_loss);
+                                   (const long long*)idx, tbox, anch, (const long long*)tcls, counts, grad_loss, owner, nxt);
             return dh_launch_status();
         }
         if (F) {
@@ -640,10 +751,10 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
         }
         if (P.cap > 0 && P.half)
             hipLaunchKernelGGL((k_yl_pos_bwd<true, _Float16>), dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P,
-                               (const long long*)idx, tbox, anch, (const long long*)tcls, counts, grad_loss);
+                               (const long long*)idx, tbox, anch, (const long long*)tcls, counts, grad_loss, owner, nxt);
         else if (P.cap > 0)
             hipLaunchKernelGGL(k_yl_pos_bwd<true>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx,
-                               tbox, anch, (const long long*)tcls, counts, grad_loss);
+                               tbox, anch, (const long long*)tcls, counts, grad_loss, owner, nxt);
         return dh_launch_status();
     }
     bool vec4 = true;
@@ -667,7 +778,7 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
     }
     if (P.cap > 0)
         hipLaunchKernelGGL(k_yl_pos_bwd<false>, dim3((unsigned)((P.cap + 3) / 4), P.nl), dim3(256), 0, st, P, (const long long*)idx, tbox,
-                           anch, (const long long*)tcls, counts, grad_loss);
+                           anch, (const long long*)tcls, counts, grad_loss, owner, nxt);
     return dh_launch_status();
 }
 

@@ -238,6 +238,52 @@ def test_forward_backward_in_two_halves_matches_the_fused_call():
         crit.forward_backward([x.clone() for x in levels], targets, positives=st)
 
 
+def test_gradient_is_bit_reproducible_on_shared_cells():
+    """Many targets on the same few cells: the rows of a cell are summed in row order by one wave, so the gradient is the
+    same bit for bit on every run (and within 1e-5 of the oracle).  A cell shared by more rows than one wave holds (here
+    120 copies of one target) takes the atomic fallback and is only compared with the oracle."""
+    from object_detection_amd.yolo_loss import ComputeLoss
+    rs = np.random.RandomState(5)
+    anchors = oy.grid_anchors()
+    levels = synth_head(rs, 4, 320, 80)
+    crowd = synth_targets(rs, 60, 4)
+    crowd[:, 2:4] = 0.5 + rs.uniform(-0.08, 0.08, (60, 2))           # 60 boxes around the centres of two images
+    crowd[:, 4:6] = rs.uniform(0.1, 0.3, (60, 2))
+    crowd[:, 0] = rs.randint(0, 2, 60)
+    hyp = dict(oy.HYP_SCRATCH)
+    crit = ComputeLoss(FakeModel(anchors.cuda(), 80, hyp))
+    d = [T(x).cuda() for x in levels]
+    tg = T(crowd).cuda()
+    l0, i0, g0 = crit.forward_backward(d, tg)
+    for cell_index in crit.build_targets(d, tg)[2]:                   # up to 7 / 15 / 24 rows on one cell of the three levels
+        rows_per_cell = np.unique(np.stack([a.cpu().numpy() for a in cell_index], 1), axis=0, return_counts=True)[1]
+        assert 3 <= rows_per_cell.max() <= 64 and (rows_per_cell >= 3).sum() > 20
+    for _ in range(4):
+        l1, i1, g1 = crit.forward_backward(d, tg)
+        assert torch.equal(l1, l0) and torch.equal(i1, i0)
+        for a, b in zip(g1, g0):
+            assert torch.equal(a, b)
+    p = [T(x).requires_grad_(True) for x in levels]
+    wl, wi = oy.YoloLossOracle(anchors, hyp, nc=80)(p, T(crowd))
+    wg = torch.autograd.grad(wl, p)
+    close(l0, wl.detach())
+    for a, b in zip(g0, wg):
+        close(a, b)
+    # the autograd path runs the same kernels
+    q = [x.clone().requires_grad_(True) for x in d]
+    la, _ = crit(q, tg)
+    for a, b in zip(torch.autograd.grad(la, q), g0):
+        assert torch.equal(a, b)
+    # more rows on one cell than a wave takes
+    many = np.repeat(crowd[:1], 120, axis=0)
+    lm, im, gm = crit.forward_backward(d, T(many).cuda())
+    wl, wi = oy.YoloLossOracle(anchors, hyp, nc=80)(p, T(many))
+    wg = torch.autograd.grad(wl, p)
+    close(lm, wl.detach())
+    for a, b in zip(gm, wg):
+        close(a, b, rtol=2e-5)
+
+
 def test_forward_backward_autobalance_golden(golden):
     """autobalance=True (loss.py:157-161) through the autograd-free entry: the reference's values call after call (the
     balance weights move between calls) and its final balance."""
