@@ -2479,6 +2479,13 @@ __global__ void __launch_bounds__(256) k_nms_prepare_f16(const _Float16* __restr
     const bool over = c0 + VEC > no;                                        // runs over into row + 1 (of the same image)
     const float obj0 = (float)p[(size_t)row * no + 4];
     const float obj1 = over ? (float)p[(size_t)(row + 1) * no + 4] : obj0;
+    // The box of the row whose channels 0..4 this vector may hold (row, or row + 1 when the vector starts beyond channel 4)
+    // is fetched by every lane, needed or not, together with the loads above: inside the branch below the four loads would
+    // be a second round trip for nearly every wave (a wave's 512 elements always contain some row's box).
+    const bool next = c0 >= 5;
+    const uint32_t rbox = min(row + (next ? 1u : 0u), per_image / no - 1);
+    const _Float16* __restrict__ pr = p + (size_t)rbox * no;
+    const float bx = (float)pr[0], by = (float)pr[1], bw = (float)pr[2], bh = (float)pr[3];
     float y[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
@@ -2486,12 +2493,9 @@ __global__ void __launch_bounds__(256) k_nms_prepare_f16(const _Float16* __restr
         y[k] = wide ? val : round_f16(val);
     }
     if (c0 < 5 || over) {
-        const bool next = c0 >= 5;
         const uint32_t r = row + (next ? 1u : 0u);
         const int k0 = next ? (int)(no - c0) : -(int)c0;                    // element of this vector where channel 0 of row r sits
-        const _Float16* __restrict__ pr = p + (size_t)r * no;
         const float obj = next ? obj1 : obj0;
-        const float bx = (float)pr[0], by = (float)pr[1], bw = (float)pr[2], bh = (float)pr[3];   // one round trip, not one per element
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const int c = k - k0;
