@@ -35,7 +35,7 @@ struct yl_level {
     float* g;            // gradient, same shape (backward only)
     int ny, nx;
     long cells;          // bs*na*ny*nx
-    long cell_first;     // offset of this level in the owner map
+    long cell_first;     // offset of this level in the per-cell map (one word per cell: the head of the cell's row list, -1 if none)
     dh_fastdiv per_image;   // na*ny*nx
     dh_fastdiv plane;       // ny*nx
     dh_fastdiv gchunks;     // convolution-layout dense gradient: workgroups per (image, anchor) span
@@ -222,7 +222,7 @@ __device__ __forceinline__ float tobj_of(const yl_params& P, int head, const flo
 #define OBJ_CELLS_PER_BLOCK 1024
 
 // VEC: a thread owns four consecutive cells (same image: the cells per image and level are a multiple of four) and
-// moves the compact logits, the owner words and the stored derivative as 16-byte vectors.
+// moves the compact logits, the cells' words and the stored derivative as 16-byte vectors.
 template <bool VEC, bool CONV = false, typename T = float>
 __global__ void __launch_bounds__(256) k_yl_obj_fwd(const yl_params P, const int* __restrict__ owner,
                                                     const int* __restrict__ nxt, const float* __restrict__ iou_ws,
@@ -667,7 +667,7 @@ extern "C" size_t dh_yolo_loss_workspace(const int* ny, const int* nx, int nl, i
 
 namespace {
 
-// forward launches; fill: set the owner map (and the two counters behind it) to -1 here, false when the caller's
+// forward launches; fill: set the per-cell map (and the two counters behind it) to -1 here, false when the caller's
 // assignment launch already did; final: run the reduction as a launch of its own
 // parts: 1 = positives, 2 = dense objectness (+ final), 3 = both
 int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx, const float* tbox, const float* anch,
@@ -680,7 +680,7 @@ int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx,
     double* partial = (double*)(ws + W.off_partial);
     int* invalid = (int*)(ws + W.off_invalid);
     int* nxt = (int*)(ws + W.off_next);
-    // one fill: owner map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
+    // one fill: per-cell map = -1 (no row), ignored-row counter = -1 (so the count is counter + 1)
     // the fill covers the region up to its 256-byte padding: a size that is a multiple of 16 is one fill kernel, not two
     if (fill && dh_fill_async(owner, 0xFF, W.off_iou - W.off_owner, st) != DH_OK) return DH_ERR_LAUNCH;
     if (P.cap > 0 && (parts & 1)) {
@@ -873,7 +873,7 @@ static int loss_fwd_bwd(int conv, const float* targets, int64_t nt, const float*
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && !dh_aligned16(tbox))) return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
-    // 1 assignment; spare workgroups of that launch set the owner map and the counters behind it to -1
+    // 1 assignment; spare workgroups of that launch set the per-cell map and the counters behind it to -1
     int rc = dh_launch_build_targets(targets, nt, anchors, nl, na, ny, nx, anchor_t, cap, idx, tbox, anch, tcls, counts,
                                      assign_workspace, assign_workspace_bytes, ws + W.off_owner, W.off_iou - W.off_owner, stream);
     if (rc != DH_OK) return rc;
