@@ -148,6 +148,105 @@ __global__ void __launch_bounds__(256) k_yolo_decode(const decode_params P, floa
     }
 }
 
+// The same decode with the box patch moved off the streaming lanes.  A wave's two spans of 256 consecutive floats hold the
+// box and objectness channels of at most `specials / 10` rows each; instead of every lane running the patch code over the four
+// components of its vectors (select chains over register components, executed by the whole wave for the few lanes that
+// need it), the wave writes its sigmoids (and logits) to a slice of LDS, lane s takes the s-th of those few special elements
+// -- (span, row, channel 0..4) -- patches it in LDS or copies it to the objectness planes, and every lane then reads its
+// vectors back and stores them.  Same arithmetic, element for element; no workgroup barrier (the slice is the wave's own).
+__device__ __forceinline__ void dh_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int NT, typename T = float>
+__global__ void __launch_bounds__(256) k_yolo_decode_lanes(const decode_params P, float* __restrict__ out, const uint32_t specials)
+{
+    __shared__ __align__(16) float s_y[4 * 512];
+    __shared__ __align__(16) float s_x[4 * 512];
+    const int b = blockIdx.y;
+    int l = 0;
+    uint32_t blk = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < DH_MAX_LEVELS - 1; ++k) {
+        if (l == k && k + 1 < P.nl && blk >= P.blocks[k]) { blk -= P.blocks[k]; l = k + 1; }
+    }
+    const decode_level& L = P.lvl[l];
+    const uint32_t nvec = L.elems / 4;
+    const uint32_t no = P.no.d;
+    const T* __restrict__ src = reinterpret_cast<const T*>(L.src) + (size_t)b * L.elems;
+    float* __restrict__ dst = out + (size_t)b * P.per_image + L.first;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t v0 = blk * 512 + threadIdx.x;
+    dh_fastdiv plane = L.plane, nxd = L.nx;
+    uint32_t stride_bits = __float_as_uint(L.stride);
+    uint32_t anc[2 * DH_MAX_ANCHORS];
+#pragma unroll
+    for (int q = 0; q < 2 * DH_MAX_ANCHORS; ++q) { anc[q] = __float_as_uint(L.anchor_px[q]); DH_PIN_SGPR(anc[q]); }
+    DH_PIN_SGPR(plane.magic); DH_PIN_SGPR(plane.shift); DH_PIN_SGPR(plane.d);
+    DH_PIN_SGPR(nxd.magic); DH_PIN_SGPR(nxd.shift); DH_PIN_SGPR(nxd.d); DH_PIN_SGPR(stride_bits);
+    const float stride = __uint_as_float(stride_bits);
+    dh_f4 x[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t v = v0 + u * 256;
+        const dh_f4 zero = {0.f, 0.f, 0.f, 0.f};
+        x[u] = v < nvec ? load4<(NT & 1) != 0>(src + (size_t)v * 4) : zero;
+    }
+    dh_f4* __restrict__ wy = reinterpret_cast<dh_f4*>(s_y + wave * 512);
+    dh_f4* __restrict__ wx = reinterpret_cast<dh_f4*>(s_x + wave * 512);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const dh_f4 y = {dh_sigmoid(x[u].x), dh_sigmoid(x[u].y), dh_sigmoid(x[u].z), dh_sigmoid(x[u].w)};
+        wy[u * 64 + lane] = y;
+        if (P.logit_plane) wx[u * 64 + lane] = x[u];
+    }
+    dh_wave_sync();
+    const uint32_t per_span = specials >> 1;
+    const uint32_t vw = blk * 512 + wave * 64;                 // first vector of the wave's first span
+    float* __restrict__ fy = s_y + wave * 512;
+    const float* __restrict__ fx = s_x + wave * 512;
+    for (uint32_t s = lane; s < specials; s += 64) {
+        const uint32_t u = s >= per_span ? 1u : 0u;
+        const uint32_t t = s - u * per_span;
+        const uint32_t ri = t / 5u, c = t - ri * 5u;
+        const uint32_t e0 = (vw + u * 256) * 4;                // first element of the span
+        const uint32_t r = dh_div(e0, P.no) + ri;
+        const uint32_t e = r * no + c;
+        if (e < e0 || e >= e0 + 256 || e >= L.elems) continue;
+        const uint32_t at = u * 256 + (e - e0);
+        const float sv = fy[at];
+        if (c < 4) {
+            const uint32_t a = dh_div(r, plane);
+            const uint32_t cell = r - a * plane.d;
+            const uint32_t gy = dh_div(cell, nxd);
+            const uint32_t gx = cell - gy * nxd.d;
+            uint32_t aw = anc[0], ah = anc[1];
+#pragma unroll
+            for (int q = 1; q < DH_MAX_ANCHORS; ++q)
+                if (a == (uint32_t)q) { aw = anc[2 * q]; ah = anc[2 * q + 1]; }
+            const float xy = (sv * 2.0f - 0.5f + (float)((c & 1) ? gy : gx)) * stride;          // yolo.py:60,66
+            const float t2 = sv * 2.0f;
+            const float wh = (t2 * t2) * __uint_as_float((c & 1) ? ah : aw);                     // yolo.py:61,67
+            fy[at] = c < 2 ? xy : wh;
+        } else if (P.obj_plane) {
+            const size_t row_at = (size_t)b * P.rows_per_image + L.row_first + r;
+            P.obj_plane[row_at] = sv;
+            if (P.logit_plane) P.logit_plane[row_at] = fx[at];
+        }
+    }
+    dh_wave_sync();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t v = v0 + u * 256;
+        if (v >= nvec) continue;
+        const dh_f4 o = wy[u * 64 + lane];
+        if (NT & 2) __builtin_nontemporal_store(o, reinterpret_cast<dh_f4*>(dst + (size_t)v * 4));
+        else *reinterpret_cast<dh_f4*>(dst + (size_t)v * 4) = o;
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -190,6 +289,17 @@ int decode_run(const float* const* level_ptrs, bool half, const int* ny, const i
         gx += P.blocks[l];
     }
     hipStream_t st = (hipStream_t)stream;
+    static const int lanes = [] {      // 0: the box patch on the streaming lanes (k_yolo_decode), the form measured slower
+        const char* n = getenv("DH_DECODE_LANES");
+        return n ? atoi(n) : 1;
+    }();
+    if (vec4 && unroll == 2 && (half ? lanes == 2 : lanes != 0)) {      // fp16 maps: measured slower (0.194 against 0.176 ms), off
+        // special elements of a wave: two spans, each touching at most (no + 254) / no + 1 rows, five channels per row
+        const uint32_t specials = 2u * 5u * (uint32_t)((no + 254) / no + 1);
+        if (half) hipLaunchKernelGGL((k_yolo_decode_lanes<3, _Float16>), dim3(gx, bs), dim3(256), 0, st, P, out, specials);
+        else hipLaunchKernelGGL((k_yolo_decode_lanes<3>), dim3(gx, bs), dim3(256), 0, st, P, out, specials);
+        return dh_launch_status();
+    }
 #define DH_DEC(U, N) do { if (half) hipLaunchKernelGGL((k_yolo_decode<4, U, N, _Float16>), dim3(gx, bs), dim3(256), 0, st, P, out); \
                           else hipLaunchKernelGGL((k_yolo_decode<4, U, N>), dim3(gx, bs), dim3(256), 0, st, P, out); } while (0)
 #define DH_DEC_NT(U) do { if (nt == 0) DH_DEC(U, 0); else if (nt == 1) DH_DEC(U, 1); else if (nt == 2) DH_DEC(U, 2); else DH_DEC(U, 3); } while (0)
