@@ -494,8 +494,9 @@ def main():
     decode_s = stage_ms["decode"] * 1e-3
     achieved = decode_bytes / decode_s / 1e9
     pmc, pmc_path = load_pmc_traffic()
-    prof_ms = pmc.get("per_launch", {}).get("k_yolo_decode", {}).get("avg_us", 0.0) / 1e3
-    roofline = {"kernel": "k_yolo_decode", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    decode_kernel = pmc.get("decode_kernel", "k_yolo_decode_lanes")      # the launch detect_decode makes for fp32 maps
+    prof_ms = pmc.get("per_launch", {}).get(decode_kernel, {}).get("avg_us", 0.0) / 1e3
+    roofline = {"kernel": decode_kernel, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "measured": "HIP events around the launch on its stream, this run (every 4th timed step)",
                 # NOT measured in this run: the PMC counters need rocprofv3; the figure is read from the committed summary

@@ -160,11 +160,11 @@ __device__ __forceinline__ void dh_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int NT, typename T = float>
+template <int U, int NT, typename T = float>
 __global__ void __launch_bounds__(256) k_yolo_decode_lanes(const decode_params P, float* __restrict__ out, const uint32_t specials)
 {
-    __shared__ __align__(16) float s_y[4 * 512];
-    __shared__ __align__(16) float s_x[4 * 512];
+    __shared__ __align__(16) float s_y[4 * U * 256];
+    __shared__ __align__(16) float s_x[4 * U * 256];
     const int b = blockIdx.y;
     int l = 0;
     uint32_t blk = blockIdx.x;
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_yolo_decode_lanes(const decode_params P
     const T* __restrict__ src = reinterpret_cast<const T*>(L.src) + (size_t)b * L.elems;
     float* __restrict__ dst = out + (size_t)b * P.per_image + L.first;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t v0 = blk * 512 + threadIdx.x;
+    const uint32_t v0 = blk * (256 * U) + threadIdx.x;
     dh_fastdiv plane = L.plane, nxd = L.nx;
     uint32_t stride_bits = __float_as_uint(L.stride);
     uint32_t anc[2 * DH_MAX_ANCHORS];
@@ -187,28 +187,28 @@ __global__ void __launch_bounds__(256) k_yolo_decode_lanes(const decode_params P
     DH_PIN_SGPR(plane.magic); DH_PIN_SGPR(plane.shift); DH_PIN_SGPR(plane.d);
     DH_PIN_SGPR(nxd.magic); DH_PIN_SGPR(nxd.shift); DH_PIN_SGPR(nxd.d); DH_PIN_SGPR(stride_bits);
     const float stride = __uint_as_float(stride_bits);
-    dh_f4 x[2];
+    dh_f4 x[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         const uint32_t v = v0 + u * 256;
         const dh_f4 zero = {0.f, 0.f, 0.f, 0.f};
         x[u] = v < nvec ? load4<(NT & 1) != 0>(src + (size_t)v * 4) : zero;
     }
-    dh_f4* __restrict__ wy = reinterpret_cast<dh_f4*>(s_y + wave * 512);
-    dh_f4* __restrict__ wx = reinterpret_cast<dh_f4*>(s_x + wave * 512);
+    dh_f4* __restrict__ wy = reinterpret_cast<dh_f4*>(s_y + wave * (U * 256));
+    dh_f4* __restrict__ wx = reinterpret_cast<dh_f4*>(s_x + wave * (U * 256));
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         const dh_f4 y = {dh_sigmoid(x[u].x), dh_sigmoid(x[u].y), dh_sigmoid(x[u].z), dh_sigmoid(x[u].w)};
         wy[u * 64 + lane] = y;
         if (P.logit_plane) wx[u * 64 + lane] = x[u];
     }
     dh_wave_sync();
-    const uint32_t per_span = specials >> 1;
-    const uint32_t vw = blk * 512 + wave * 64;                 // first vector of the wave's first span
-    float* __restrict__ fy = s_y + wave * 512;
-    const float* __restrict__ fx = s_x + wave * 512;
+    const uint32_t per_span = specials / U;
+    const uint32_t vw = blk * (256 * U) + wave * 64;           // first vector of the wave's first span
+    float* __restrict__ fy = s_y + wave * (U * 256);
+    const float* __restrict__ fx = s_x + wave * (U * 256);
     for (uint32_t s = lane; s < specials; s += 64) {
-        const uint32_t u = s >= per_span ? 1u : 0u;
+        const uint32_t u = s / per_span;
         const uint32_t t = s - u * per_span;
         const uint32_t ri = t / 5u, c = t - ri * 5u;
         const uint32_t e0 = (vw + u * 256) * 4;                // first element of the span
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(256) k_yolo_decode_lanes(const decode_params P
     }
     dh_wave_sync();
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < U; ++u) {
         const uint32_t v = v0 + u * 256;
         if (v >= nvec) continue;
         const dh_f4 o = wy[u * 64 + lane];
@@ -293,11 +293,13 @@ int decode_run(const float* const* level_ptrs, bool half, const int* ny, const i
         const char* n = getenv("DH_DECODE_LANES");
         return n ? atoi(n) : 1;
     }();
-    if (vec4 && unroll == 2 && (half ? lanes == 2 : lanes != 0)) {      // fp16 maps: measured slower (0.194 against 0.176 ms), off
-        // special elements of a wave: two spans, each touching at most (no + 254) / no + 1 rows, five channels per row
-        const uint32_t specials = 2u * 5u * (uint32_t)((no + 254) / no + 1);
-        if (half) hipLaunchKernelGGL((k_yolo_decode_lanes<3, _Float16>), dim3(gx, bs), dim3(256), 0, st, P, out, specials);
-        else hipLaunchKernelGGL((k_yolo_decode_lanes<3>), dim3(gx, bs), dim3(256), 0, st, P, out, specials);
+    if (vec4 && (unroll == 1 || unroll == 2 || unroll == 4) && (half ? lanes == 2 : lanes != 0)) {      // fp16 maps: measured slower (0.194 against 0.176 ms), off
+        // special elements of a wave: `unroll` spans, each touching at most (no + 254) / no + 1 rows, five channels per row
+        const uint32_t specials = (uint32_t)unroll * 5u * (uint32_t)((no + 254) / no + 1);
+#define DH_LANES(U) do { if (half) hipLaunchKernelGGL((k_yolo_decode_lanes<U, 3, _Float16>), dim3(gx, bs), dim3(256), 0, st, P, out, specials); \
+                         else hipLaunchKernelGGL((k_yolo_decode_lanes<U, 3>), dim3(gx, bs), dim3(256), 0, st, P, out, specials); } while (0)
+        if (unroll == 1) DH_LANES(1); else if (unroll == 2) DH_LANES(2); else DH_LANES(4);
+#undef DH_LANES
         return dh_launch_status();
     }
 #define DH_DEC(U, N) do { if (half) hipLaunchKernelGGL((k_yolo_decode<4, U, N, _Float16>), dim3(gx, bs), dim3(256), 0, st, P, out); \

@@ -63,7 +63,9 @@ for k in sorted(fetch):
     calls, total = avg_us.get(k, (1, 0.0))
     out["per_launch"][k] = {"FETCH_SIZE_KiB": round(st.mean(fetch[k]), 1), "WRITE_SIZE_KiB": round(st.mean(write.get(k, [0])), 1),
                             "avg_us": round(total / calls / 1e3, 1), "calls": calls}
-d = out["per_launch"]["k_yolo_decode"]
+decode_kernel = "k_yolo_decode_lanes" if "k_yolo_decode_lanes" in out["per_launch"] else "k_yolo_decode"      # whichever form ran
+out["decode_kernel"] = decode_kernel
+d = out["per_launch"][decode_kernel]
 out["k_yolo_decode_bytes_per_launch"] = int(d["FETCH_SIZE_KiB"] * 1024 * 2 + d["WRITE_SIZE_KiB"] * 1024)
 out["k_yolo_decode_algorithmic_bytes_per_launch"] = 680 * 25200 * 64
 out["k_yolo_decode_note"] = ("680 B/anchor = 85 fp32 read + 85 fp32 written; on top of that the launch writes two 4 B/anchor compact "
