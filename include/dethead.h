@@ -248,11 +248,14 @@ int dh_build_targets(const float* targets, int64_t nt, const float* anchors, int
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Hyper-parameters of ComputeLoss (loss.py:93-115): gains box/obj/cls, BCE pos_weights, focal gamma
- * (0 = plain BCE), smoothed class targets cp/cn (loss.py:13-15,103), iou ratio gr (loss.py:113) and the
- * per-level objectness balance (loss.py:111). */
+ * (0 = plain BCE), smoothed class targets cp/cn (loss.py:13-15,103), iou ratio gr (loss.py:113), the
+ * per-level objectness balance (loss.py:111) and sort_obj_iou (loss.py:94,140-142; non-zero: where several
+ * assigned rows share a cell, the objectness target comes from the row with the largest IoU instead of from
+ * the last row). */
 typedef struct dh_yolo_hyp {
     float box, obj, cls, cls_pw, obj_pw, fl_gamma, cp, cn, gr;
     float balance[DH_MAX_LEVELS];
+    int sort_obj_iou;
 } dh_yolo_hyp;
 
 /* ComputeLoss.__call__ (loss.py:117-167) given the assignment produced by dh_build_targets.

@@ -224,7 +224,7 @@ def workspace(nbytes, device):
 class YoloHyp(ctypes.Structure):
     """Mirror of dh_yolo_hyp in include/dethead.h."""
     _fields_ = [(n, c_float) for n in ("box", "obj", "cls", "cls_pw", "obj_pw", "fl_gamma", "cp", "cn", "gr")] + [
-        ("balance", c_float * 5)]
+        ("balance", c_float * 5), ("sort_obj_iou", c_int)]
 
 
 _ARRAYS = {}

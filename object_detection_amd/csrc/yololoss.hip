@@ -54,6 +54,7 @@ struct yl_params {
     uint32_t rows_per_image;   // A = sum over levels of na*ny*nx
     long cap;
     float box, obj, cls, cls_pw, obj_pw, gamma, cp, cn, gr;
+    int sort_iou;              // the best IoU among a cell's rows owns the cell instead of its last row (loss.py:140-142)
 };
 
 #define FOCAL_ALPHA 0.25f   // default alpha of FocalLoss (loss.py:37); ComputeLoss never overrides it
@@ -216,7 +217,18 @@ __device__ __forceinline__ float tobj_of(const yl_params& P, int head, const flo
                                          const int* __restrict__ nxt_l)
 {
     if (head < 0) return 0.0f;
-    return (1.0f - P.gr) + P.gr * fmaxf(iou_l[last_row_of(head, nxt_l, P.cap)], 0.0f);           // loss.py:139,143
+    float score;
+    if (P.sort_iou) {            // rows sorted by ascending clamped IoU before index_put_: the largest one is written last
+        score = 0.0f;            // (loss.py:139-143); equal scores write equal values, so their order does not matter
+        long steps = 0;
+        for (int j = head; j >= 0 && steps < P.cap; ++steps) {
+            score = fmaxf(score, iou_l[j]);
+            j = nxt_l[j];
+        }
+    } else {
+        score = fmaxf(iou_l[last_row_of(head, nxt_l, P.cap)], 0.0f);                              // loss.py:139
+    }
+    return (1.0f - P.gr) + P.gr * score;                                                          // loss.py:143
 }
 
 #define OBJ_CELLS_PER_BLOCK 1024
@@ -599,6 +611,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
     if (hyp) {
         P.box = hyp->box; P.obj = hyp->obj; P.cls = hyp->cls; P.cls_pw = hyp->cls_pw; P.obj_pw = hyp->obj_pw;
         P.gamma = hyp->fl_gamma; P.cp = hyp->cp; P.cn = hyp->cn; P.gr = hyp->gr;
+        P.sort_iou = hyp->sort_obj_iou != 0;
     }
     long first = 0;
     unsigned blocks = 0;

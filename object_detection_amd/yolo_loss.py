@@ -339,6 +339,7 @@ class ComputeLoss:
         s.cp, s.cn, s.gr = float(self.cp), float(self.cn), float(self.gr)
         for i, b in enumerate(self.balance[:self.nl]):
             s.balance[i] = float(b)
+        s.sort_obj_iou = int(bool(self.sort_obj_iou))                           # loss.py:94,140-142
         return s
 
     def assign(self, p, targets):
@@ -359,8 +360,6 @@ class ComputeLoss:
         return assignment
 
     def __call__(self, p, targets, assignment=None):
-        if self.sort_obj_iou:
-            raise NotImplementedError("sort_obj_iou=True is not supported (the reference never enables it, loss.py:94)")
         shapes = [(int(x.shape[2]), int(x.shape[3])) for x in p]
         assign = self._assignment_for(shapes, targets, assignment)
         self.last_positive_counts = assign.counts            # (nl,) int32 on the device: rows assigned per level
@@ -377,8 +376,6 @@ class ComputeLoss:
         the assigned rows, which read only the targets and the raw maps.  Enqueue it on a side stream beside whatever
         produces or decodes `p`, make the main stream wait for it (an event), and hand the result to
         forward_backward(..., positives=...), which then only runs the dense objectness pass and the backward."""
-        if self.sort_obj_iou:
-            raise NotImplementedError("sort_obj_iou=True is not supported (the reference never enables it, loss.py:94)")
         maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
         shapes = [(int(x.shape[2]), int(x.shape[3])) for x in maps]
         return _loss_positives(shapes, targets, self.anchors, self.hyp['anchor_t'], self._hyp_struct(), int(self.nc), maps)
@@ -390,8 +387,6 @@ class ComputeLoss:
         the device, default 1) is the upstream gradient of the loss.  Everything stays on the calling stream with no
         host synchronisation and no hop to the autograd engine's device thread.
         """
-        if self.sort_obj_iou:
-            raise NotImplementedError("sort_obj_iou=True is not supported (the reference never enables it, loss.py:94)")
         convs = conv_layout_of(p) if assignment is None and positives is None else None
         if convs is not None:       # lazy maps (see conv_layout_of): gradients come back as views of the same kind
             shapes = [(int(x.shape[2]), int(x.shape[3])) for x in p]

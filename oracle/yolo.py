@@ -140,6 +140,7 @@ class YoloLossOracle:
         eps = self.hyp.get("label_smoothing", 0.0)
         self.cp, self.cn = 1.0 - 0.5 * eps, 0.5 * eps                                 # loss.py:13-15
         self.gr = 1.0
+        self.sort_obj_iou = False
 
     def _bce(self, logits, target, pos_weight):
         pw = torch.tensor([pos_weight])
@@ -168,7 +169,11 @@ class YoloLossOracle:
                 pbox = torch.cat((pxy, pwh), 1)
                 iou = bbox_iou_yolo(pbox.T, torch.from_numpy(t["tbox"]), x1y1x2y2=False, CIoU=True)
                 lbox = lbox + (1.0 - iou).mean()                                       # loss.py:136
-                tobj[b, a, gj, gi] = (1.0 - self.gr) + self.gr * iou.detach().clamp(0).type(tobj.dtype)
+                score_iou = iou.detach().clamp(0).type(tobj.dtype)
+                if self.sort_obj_iou:                                                  # loss.py:140-142
+                    order = torch.argsort(score_iou)
+                    b, a, gj, gi, score_iou = b[order], a[order], gj[order], gi[order], score_iou[order]
+                tobj[b, a, gj, gi] = (1.0 - self.gr) + self.gr * score_iou             # loss.py:143
                 if self.nc > 1:                                                        # loss.py:146-149
                     tc = torch.full_like(ps[:, 5:], self.cn)
                     tc[range(n), torch.from_numpy(t["tcls"])] = self.cp

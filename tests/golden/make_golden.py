@@ -337,10 +337,15 @@ def gen_compute_loss(y_loss):
     anchors, strides = yolo_anchors()
     out = {"anchors": anchors.numpy()}
 
-    def run(tag, img, bs, nc, targets, hyp_over=None, autobalance=False, calls=1, store_grads=True):
+    def run(tag, img, bs, nc, targets, hyp_over=None, autobalance=False, calls=1, store_grads=True, sort_obj_iou=False,
+            gr=None):
         hyp = dict(HYP)
         hyp.update(hyp_over or {})
         cl = y_loss.ComputeLoss(fake_model(y_loss, nc, hyp, anchors, strides), autobalance=autobalance)
+        if sort_obj_iou or gr is not None:      # the two attributes a caller may set on the object (loss.py:94,113)
+            cl.sort_obj_iou = bool(sort_obj_iou)
+            cl.gr = cl.gr if gr is None else float(gr)
+            out[f"{tag}_opts"] = np.array([float(cl.sort_obj_iou), cl.gr])
         levels = synth_head(rs, bs, img, nc)
         out[f"{tag}_targets"] = targets
         out[f"{tag}_meta"] = np.array([img, bs, nc, int(autobalance), calls])
@@ -372,6 +377,16 @@ def gen_compute_loss(y_loss):
     run("posw", 64, 2, 12, t64, {"cls_pw": 0.7, "obj_pw": 1.3, "box": 0.07, "cls": 0.3, "obj": 0.8})
     run("autobal", 64, 2, 12, t64, None, autobalance=True, calls=2)
     run("nc1", 64, 2, 1, np.concatenate([t64[:, :1], np.zeros((10, 1), np.float32), t64[:, 2:]], 1))
+    # sort_obj_iou: the best IoU among the rows of a cell owns it instead of the last row.  Cells with up to six rows whose
+    # sizes (hence IoUs) differ, listed so that the last row is not the best one.
+    tsort = synth_targets(rs, 30, 2, 80)
+    for k, f in ((9, 1.0), (10, 1.3), (11, 0.8), (12, 1.15), (13, 0.7)):
+        tsort[k] = tsort[8]
+        tsort[k, 4:6] = tsort[8, 4:6] * f
+    tsort[21] = tsort[20]; tsort[21, 4:6] = tsort[20, 4:6] * 1.4
+    run("sortiou", 128, 2, 80, tsort, sort_obj_iou=True)
+    run("sortiou_gr", 128, 2, 80, tsort, sort_obj_iou=True, gr=0.5)
+    run("gr_half", 128, 2, 80, tsort, gr=0.5)
     save("compute_loss", **out)
 
 
@@ -925,7 +940,8 @@ def main():
     only = set(sys.argv[1:])
     if only:                      # e.g. `make_golden.py ap`: regenerate the named fixtures only
         gens = {"ap": lambda: gen_ap(y_metrics), "evalmatch": lambda: gen_evalmatch(y_metrics), "tta": gen_tta,
-                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss), "nms_merge": lambda: gen_nms_merge(y_general), "detect": lambda: gen_detect(y_general), "half": lambda: gen_half(y_general)}
+                "autoanchor": gen_autoanchor, "focal": lambda: gen_focal(a_loss), "nms_merge": lambda: gen_nms_merge(y_general), "detect": lambda: gen_detect(y_general), "half": lambda: gen_half(y_general),
+                "compute_loss": lambda: gen_compute_loss(y_loss)}
         for k in only:
             gens[k]()
         return

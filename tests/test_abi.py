@@ -27,6 +27,23 @@ def test_library_exports_every_declared_symbol():
     _lib.lib()
 
 
+def test_hyp_struct_layout_matches_the_header(tmp_path):
+    """The ctypes mirror of dh_yolo_hyp has the size and field offsets the C compiler gives the header's struct."""
+    import subprocess
+    from object_detection_amd import _lib
+    fields = [n for n, _ in _lib.YoloHyp._fields_]
+    src = tmp_path / "layout.c"
+    prints = "".join(f'printf("{n} %zu\\n", offsetof(dh_yolo_hyp, {n}));' for n in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dethead.h"\n'
+                   f'int main(void) {{ printf("size %zu\\n", sizeof(dh_yolo_hyp)); {prints} return 0; }}\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got["size"]) == ctypes.sizeof(_lib.YoloHyp)
+    for n in fields:
+        assert int(got[n]) == getattr(_lib.YoloHyp, n).offset, n
+
+
 def test_no_cpu_fallback():
     from object_detection_amd.metrics import bbox_iou
     with pytest.raises(RuntimeError, match="no CPU fallback"):

@@ -79,12 +79,23 @@ def test_build_targets_bs64_vs_oracle():
     assert sum(len(w["b"]) for w in want) > 3000
 
 
-@pytest.mark.parametrize("tag", ["base128", "nt0", "smooth", "focal", "posw", "autobal", "nc1"])
-def test_compute_loss_golden(golden, tag):
-    g = golden("compute_loss")
+LOSS_TAGS = ["base128", "nt0", "smooth", "focal", "posw", "autobal", "nc1", "sortiou", "sortiou_gr", "gr_half"]
+
+
+def golden_loss(g, tag):
+    """The criterion a fixture case was made with: constructor arguments, then the attributes set on the object."""
     img, bs, nc, autobal, calls = (int(v) for v in g[f"{tag}_meta"])
     hyp = dict(zip(HYP_KEYS, (float(v) for v in g[f"{tag}_hyp"])))
     crit = make_loss(T(g["anchors"]), nc, hyp, bool(autobal))
+    if f"{tag}_opts" in g:                                   # loss.py:94,113
+        crit.sort_obj_iou, crit.gr = bool(g[f"{tag}_opts"][0]), float(g[f"{tag}_opts"][1])
+    return crit, autobal, calls
+
+
+@pytest.mark.parametrize("tag", LOSS_TAGS)
+def test_compute_loss_golden(golden, tag):
+    g = golden("compute_loss")
+    crit, autobal, calls = golden_loss(g, tag)
     for c in range(calls):
         p = [T(g[f"{tag}_p{l}"]).cuda().requires_grad_(True) for l in range(3)]
         loss, items = crit(p, T(g[f"{tag}_targets"]).reshape(-1, 6).cuda())
@@ -301,3 +312,68 @@ def test_forward_backward_autobalance_golden(golden):
         for l in range(3):
             close(grads[l], g[f"{tag}_call{c}_grad{l}"])
     close(np.array(crit.balance), g[f"{tag}_balance"])
+
+
+@pytest.mark.parametrize("tag", ["sortiou", "sortiou_gr", "gr_half"])
+def test_forward_backward_sort_obj_iou_golden(golden, tag):
+    """sort_obj_iou / gr set on the object (loss.py:94,113,140-143) through the autograd-free entry and through its two
+    halves: the reference's values."""
+    g = golden("compute_loss")
+    crit, _, _ = golden_loss(g, tag)
+    p = [T(g[f"{tag}_p{l}"]).cuda() for l in range(3)]
+    tg = T(g[f"{tag}_targets"]).reshape(-1, 6).cuda()
+    for halves in (False, True):
+        kw = dict(positives=crit.positives(p, tg)) if halves else {}
+        loss, items, grads = crit.forward_backward(p, tg, **kw)
+        close(loss, g[f"{tag}_call0_loss"])
+        close(items, g[f"{tag}_call0_items"])
+        for l in range(3):
+            close(grads[l], g[f"{tag}_call0_grad{l}"])
+
+
+def test_sort_obj_iou_on_crowded_cells_vs_oracle():
+    """Up to 24 rows on one cell, and 120 copies of one target: with sort_obj_iou the cell's objectness target is that of
+    its best row, whichever path (list walk or atomic fallback) the gradient takes; also on the convolution layout."""
+    from object_detection_amd.yolo_loss import ComputeLoss, conv_layout_of
+    rs = np.random.RandomState(5)
+    anchors = oy.grid_anchors()
+    levels = synth_head(rs, 4, 320, 80)
+    crowd = synth_targets(rs, 60, 4)
+    crowd[:, 2:4] = 0.5 + rs.uniform(-0.08, 0.08, (60, 2))
+    crowd[:, 4:6] = rs.uniform(0.1, 0.3, (60, 2))
+    crowd[:, 0] = rs.randint(0, 2, 60)
+    many = np.repeat(crowd[:1], 120, axis=0)
+    many[:, 4:6] *= rs.uniform(0.7, 1.4, (120, 1)).astype(np.float32)
+    hyp = dict(oy.HYP_SCRATCH)
+    crit = ComputeLoss(FakeModel(anchors.cuda(), 80, hyp))
+    crit.sort_obj_iou, crit.gr = True, 0.75
+    want_fn = oy.YoloLossOracle(anchors, hyp, nc=80)
+    want_fn.sort_obj_iou, want_fn.gr = True, 0.75
+    plain = oy.YoloLossOracle(anchors, hyp, nc=80)
+    plain.gr = 0.75
+    d = [T(x).cuda() for x in levels]
+    for targets in (crowd, many):
+        p = [T(x).requires_grad_(True) for x in levels]
+        wl, wi = want_fn(p, T(targets))
+        wg = torch.autograd.grad(wl, p)
+        assert abs(float(plain(p, T(targets))[1][1]) - float(wi[1])) > 1e-4 * float(wi[1])    # the flag matters here
+        loss, items, grads = crit.forward_backward(d, T(targets).cuda())
+        close(loss, wl.detach())
+        close(items, wi)
+        for a, b in zip(grads, wg):
+            close(a, b, rtol=2e-5)
+        q = [x.clone().requires_grad_(True) for x in d]
+        la, ia = crit(q, T(targets).cuda())
+        close(la, wl.detach())
+        close(ia, wi)
+        for a, b in zip(torch.autograd.grad(la, q), wg):
+            close(a, b, rtol=2e-5)
+        # the same maps as permuted views of convolution outputs (bs, na*no, ny, nx)
+        convs = [x.permute(0, 1, 4, 2, 3).reshape(x.shape[0], -1, x.shape[2], x.shape[3]).contiguous() for x in d]
+        views = [c.view(c.shape[0], 3, 85, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2) for c in convs]
+        assert conv_layout_of(views) is not None
+        lc, ic, gc = crit.forward_backward(views, T(targets).cuda())
+        close(lc, wl.detach())
+        close(ic, wi)
+        for a, b in zip(gc, wg):
+            close(a, b, rtol=2e-5)

@@ -94,12 +94,17 @@ def test_build_targets(golden, tag):
 HYP_KEYS = ("box", "cls", "cls_pw", "obj", "obj_pw", "anchor_t", "fl_gamma", "label_smoothing")
 
 
-@pytest.mark.parametrize("tag", ["base128", "nt0", "smooth", "focal", "posw", "autobal", "nc1"])
+LOSS_TAGS = ["base128", "nt0", "smooth", "focal", "posw", "autobal", "nc1", "sortiou", "sortiou_gr", "gr_half"]
+
+
+@pytest.mark.parametrize("tag", LOSS_TAGS)
 def test_compute_loss(golden, tag):
     g = golden("compute_loss")
     img, bs, nc, autobal, calls = (int(v) for v in g[f"{tag}_meta"])
     hyp = dict(zip(HYP_KEYS, (float(v) for v in g[f"{tag}_hyp"])))
     crit = oy.YoloLossOracle(T(g["anchors"]), hyp, nc=nc, autobalance=bool(autobal))
+    if f"{tag}_opts" in g:                      # attributes set on the object after construction (loss.py:94,113)
+        crit.sort_obj_iou, crit.gr = bool(g[f"{tag}_opts"][0]), float(g[f"{tag}_opts"][1])
     for c in range(calls):
         p = [T(g[f"{tag}_p{l}"]).requires_grad_(True) for l in range(3)]
         loss, items = crit(p, T(g[f"{tag}_targets"]).reshape(-1, 6))
@@ -110,6 +115,19 @@ def test_compute_loss(golden, tag):
             close(grads[l], g[f"{tag}_call{c}_grad{l}"], atol=1e-9)
     if autobal:
         close(np.array(crit.balance), g[f"{tag}_balance"])
+
+
+def test_compute_loss_sort_obj_iou_case_discriminates(golden):
+    """The sorted case would not pass with last-writer-wins: its objectness loss differs when the flag is off."""
+    g = golden("compute_loss")
+    tag = "sortiou"
+    nc = int(g[f"{tag}_meta"][2])
+    hyp = dict(zip(HYP_KEYS, (float(v) for v in g[f"{tag}_hyp"])))
+    crit = oy.YoloLossOracle(T(g["anchors"]), hyp, nc=nc)
+    _, items = crit([T(g[f"{tag}_p{l}"]) for l in range(3)], T(g[f"{tag}_targets"]).reshape(-1, 6))
+    want = g[f"{tag}_call0_items"]
+    assert abs(float(items[1]) - float(want[1])) > 1e-4 * float(want[1])
+    np.testing.assert_allclose(items[0].numpy(), want[0], rtol=1e-6)
 
 
 def unpack(g, key):
