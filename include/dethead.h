@@ -176,6 +176,18 @@ int dh_yolo_decode_nms_f16(const void* const* level_ptrs, const int* ny, const i
                            int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* The same on fp16 level maps with the arithmetic of a half-precision model (model.half(),
+ * object_detection/yolov5/val.py:129-130): what dh_yolo_decode_half (in-place form) followed by dh_nms_prepare_f16 and
+ * dh_nms_batched_prepared produce, bit for bit, without the fp16 decoded tensor or its fp32 copy -- the sigmoid rounded to
+ * fp16 (yolo.py:58), the box with the roundings of yolo.py:59-61, conf = obj * cls rounded to fp16
+ * (utils/general.py:691), the corners formed in fp16 (general.py:694,553-560), fp32 from there on.  anchor_px as for
+ * dh_yolo_decode_half: (anchors.half() * stride).float(). */
+int dh_yolo_decode_nms_half(const void* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                            const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
+                            int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+                            int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
 /* The same fed by the outputs of the head's 1x1 convolutions, conv_ptrs[l] = (bs, na*no, ny, nx) contiguous, i.e. the
  * tensors Detect.forward holds before the layout change of object_detection/yolov5/models/yolo.py:54: neither the head
  * maps nor the decoded tensor are written or read.  The candidate search reads the objectness planes (contiguous in this

@@ -327,8 +327,6 @@ int decode_run(const float* const* level_ptrs, bool half, const int* ny, const i
 // _make_grid holds on such a model: (anchors.half() * stride).float().
 namespace {
 
-__device__ __forceinline__ float dh_round_f16(float v) { return (float)(_Float16)v; }
-
 // one thread: VEC consecutive elements of one level of one image (VEC = 4: one 8-byte load).  OUT = _Float16: the in-place
 // form (yolo.py:59-61), every value rounded into the fp16 tensor.  OUT = float: the torch.cat form (yolo.py:63-65), where
 // xy and wh stay the fp32 values they were computed as and the cat widens the fp16 rest.

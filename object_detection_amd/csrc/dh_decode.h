@@ -30,6 +30,25 @@ __device__ __forceinline__ float decode_box(const decode_level& L, uint32_t row,
     return c < 2 ? xy : wh;
 }
 
+// The same behind a half-precision model (model.half(), val.py:129-130; yolo.py:59-61 in place): the maps and the sigmoid
+// are fp16, grid, stride and anchor grid are float tensors, so torch rounds to fp16 after the sigmoid (s comes in rounded),
+// after *2 (exact), after -0.5 and after **2, widens for + grid, * stride and * anchor_grid, and rounds once more when the
+// result is assigned into the fp16 tensor.  anchor_px must be what such a model holds: (anchors.half() * stride).float().
+__device__ __forceinline__ float dh_round_f16(float v) { return (float)(_Float16)v; }
+
+__device__ __forceinline__ float decode_box_half(const decode_level& L, uint32_t row, uint32_t c, float s)
+{
+    const uint32_t a = dh_div(row, L.plane);
+    const uint32_t cell = row - a * L.plane.d;
+    const uint32_t gy = dh_div(cell, L.nx);
+    const uint32_t gx = cell - gy * L.nx.d;
+    const float g = (float)((c & 1u) ? gy : gx);
+    const float t = s * 2.0f;
+    const float xy = (dh_round_f16(t - 0.5f) + g) * L.stride;
+    const float wh = dh_round_f16(t * t) * L.anchor_px[2 * a + (c & 1u)];
+    return dh_round_f16(c < 2 ? xy : wh);
+}
+
 // Fills the level records from the host-side description; returns false on an unsupported shape.
 // vec4_ok (optional) reports whether every level span is a multiple of 4 elements and aligned for a 4-element load
 // (align_mask 15 for fp32 maps, 7 for fp16 maps).

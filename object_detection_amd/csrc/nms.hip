@@ -81,6 +81,7 @@ struct nms_source {
     int conv_na;     // 0: lvl[].src are head maps (bs, na, ny, nx, no); na > 0: they are the outputs of the head's 1x1
                      // convolutions, (bs, na*no, ny, nx), where channel c of a row sits ny*nx elements after channel c - 1
     int corners;     // pred rows hold the corners x1, y1, x2, y2 already (k_nms_prepare_f16), not centre and size
+    int half_arith;  // fp16 raw maps only: the roundings of a half-precision model and of NMS on its fp16 tensor (below)
 };
 
 // channels 0..3 of a row of the decoded tensor as corners (general.py:553-560)
@@ -141,6 +142,41 @@ __device__ __forceinline__ raw_row<T> raw_row_of(const nms_source& S, int b, int
     return r;
 }
 
+// Arithmetic of the fused path on raw maps.  HALF = false: fp32 throughout (fp16 maps are widened on load).  HALF = true:
+// what the reference computes behind model.half() (val.py:129-130) -- the sigmoid rounded into the fp16 tensor
+// (yolo.py:58), the box of decode_box_half, conf = obj * cls rounded to fp16 (general.py:691) and the corners formed in fp16
+// (general.py:694,553-560); thresholds are compared in fp32 and everything after the detection matrix is fp32, as in
+// k_nms_prepare_f16, whose results on the decoded fp16 tensor this reproduces bit for bit.
+template <bool HALF> __device__ __forceinline__ float act_of(float x)
+{
+    const float s = dh_sigmoid(x);                                   // yolo.py:58,62
+    return HALF ? dh_round_f16(s) : s;
+}
+template <bool HALF> __device__ __forceinline__ float conf_of(float cls, float obj)
+{
+    const float p = cls * obj;                                       // general.py:691 (exact in fp32 for two fp16 factors)
+    return HALF ? dh_round_f16(p) : p;
+}
+
+// corners of raw row `anchor` of image b (general.py:553-560 on the decoded row)
+template <typename T>
+__device__ __forceinline__ float4 raw_corners(const nms_source& S, int b, uint32_t anchor)
+{
+    const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
+    const decode_level& L = S.lvl[rr.l];
+    const float sx = dh_sigmoid(ldf(rr.p)), sy = dh_sigmoid(ldf(rr.p + rr.cs));
+    const float sw = dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)), sh = dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs));
+    if (sizeof(T) == 2 && S.half_arith) {
+        const float x = decode_box_half(L, rr.local, 0, dh_round_f16(sx)), y = decode_box_half(L, rr.local, 1, dh_round_f16(sy));
+        const float hw = dh_round_f16(decode_box_half(L, rr.local, 2, dh_round_f16(sw)) / 2);
+        const float hh = dh_round_f16(decode_box_half(L, rr.local, 3, dh_round_f16(sh)) / 2);
+        return make_float4(dh_round_f16(x - hw), dh_round_f16(y - hh), dh_round_f16(x + hw), dh_round_f16(y + hh));
+    }
+    const float x = decode_box(L, rr.local, 0, sx), y = decode_box(L, rr.local, 1, sy);
+    const float w = decode_box(L, rr.local, 2, sw), h = decode_box(L, rr.local, 3, sh);
+    return make_float4(x - w / 2, y - h / 2, x + w / 2, y + h / 2);
+}
+
 // ------------------------------------------------------------------------------------------ 1 prefilter
 struct row_best {
     float v;
@@ -174,7 +210,7 @@ __device__ __forceinline__ void wave_sync()
 // NCH > 0: the class scores of the rows in flight are fetched up front as NCH chunks of 64 classes
 // (nc <= 64*NCH), which keeps 4*NCH independent loads in flight per wave; NCH = 0 handles any nc
 // chunk by chunk.
-template <bool MULTI, int NCH, bool RAW, typename T = float>
+template <bool MULTI, int NCH, bool RAW, typename T = float, bool HALF = false>
 __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const float* __restrict__ obj_plane,
                                                        int A, int nc, float conf,
                                                        const unsigned char* __restrict__ class_keep, int cap,
@@ -202,7 +238,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
         float obj = 0.0f;
         if (row < A) {
             // the strided column is touched once: non-temporal loads fetch single 64-byte sectors (2.2x faster cold)
-            if (RAW) obj = dh_sigmoid(ldf_nt(raw_row_of<T>(S, b, row).p + 4));
+            if (RAW) obj = act_of<HALF>(ldf_nt(raw_row_of<T>(S, b, row).p + 4));
             else obj = obj_plane ? obj_plane[(size_t)b * A + row] : __builtin_nontemporal_load(img + (size_t)row * no + 4);
         }
         const bool cand = (row < A) && (obj > conf);                       // general.py:656,675
@@ -283,7 +319,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
                 if (rr * no < n_el) {
                     const float* __restrict__ rowp = tile + rr * no + 5;
                     for (int c = part; c < nc; c += 4) {
-                        const float sc = (RAW ? dh_sigmoid(rowp[c]) : rowp[c]) * myo;            // yolo.py:62, general.py:691
+                        const float sc = RAW ? conf_of<HALF>(act_of<HALF>(rowp[c]), myo) : rowp[c] * myo;   // yolo.py:62, general.py:691
                         if (sc > qv) { qv = sc; qc = c; }
                     }
                 }
@@ -334,13 +370,13 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
 #pragma unroll
                     for (int h = 0; h < NCH * 4; ++h) {
                         const int c = h * 16 + j;
-                        const float sc = (RAW ? dh_sigmoid(pre16[h]) : pre16[h]) * myo;            // yolo.py:62, general.py:691
+                        const float sc = RAW ? conf_of<HALF>(act_of<HALF>(pre16[h]), myo) : pre16[h] * myo;   // yolo.py:62, general.py:691
                         if (c < nc && sc > qv) { qv = sc; qc = c; }
                     }
                 } else {
                     for (int c = j; c < nc; c += 16) {
                         const float x = ldf(qp + c);
-                        const float sc = (RAW ? dh_sigmoid(x) : x) * myo;
+                        const float sc = RAW ? conf_of<HALF>(act_of<HALF>(x), myo) : x * myo;
                         if (sc > qv) { qv = sc; qc = c; }
                     }
                 }
@@ -384,12 +420,12 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
                 for (int k = 0; k < 4; ++k) {
                     if (NCH > 0) v[k] = pre[k][NCH > 0 ? h : 0];
                     else v[k] = (c < nc) ? ldf(rp[k] + c) : 0.0f;
-                    if (RAW) v[k] = dh_sigmoid(v[k]);          // yolo.py:62
+                    if (RAW) v[k] = act_of<HALF>(v[k]);        // yolo.py:62
                 }
                 const bool keepc = (c < nc) && (class_keep == nullptr || class_keep[c] != 0);   // general.py:705-706
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float s = v[k] * o[k];                                               // general.py:691
+                    const float s = conf_of<HALF>(v[k], o[k]);                                 // general.py:691
                     if (MULTI) {
                         const bool pass = (k < nr) && keepc && (s > conf);                     // general.py:698
                         const u64 pm = __ballot(pass);
@@ -705,7 +741,7 @@ struct stream_params {
 
 // Which of a vector's four elements are candidates, bit k for element k, and their scores: channel c0 + k of a row whose
 // objectness o is above the threshold.
-template <bool RAW>
+template <bool RAW, bool HALF>
 __device__ __forceinline__ uint32_t stream_exact(const dh_f4 x, float o, uint32_t c0, uint32_t no, float conf,
                                                  const unsigned char* __restrict__ class_keep, float sc[4])
 {
@@ -714,7 +750,7 @@ __device__ __forceinline__ uint32_t stream_exact(const dh_f4 x, float o, uint32_
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t c = c0 + k - 5u;                              // class, if the channel is in [5, no)
-        sc[k] = (RAW ? dh_sigmoid(xs[k]) : xs[k]) * o;               // yolo.py:62, general.py:691
+        sc[k] = RAW ? conf_of<HALF>(act_of<HALF>(xs[k]), o) : xs[k] * o;   // yolo.py:62, general.py:691
         bool ok = c < no - 5u && sc[k] > conf;                       // general.py:698
         if (class_keep != nullptr && ok) ok = class_keep[c] != 0;    // general.py:705-706
         bits |= ok ? 1u << k : 0u;
@@ -723,7 +759,7 @@ __device__ __forceinline__ uint32_t stream_exact(const dh_f4 x, float o, uint32_
 }
 
 // One lane's vector straight to the image's key list, for the rare lane that finds its wave's queue full.
-template <bool RAW>
+template <bool RAW, bool HALF>
 __device__ __attribute__((noinline)) void stream_direct(const dh_f4 x, float o, uint32_t v, uint32_t c0, const dh_fastdiv no,
                                                         float conf, const unsigned char* __restrict__ class_keep,
                                                         uint32_t row_first, int nc, int* __restrict__ count, int cap,
@@ -731,7 +767,7 @@ __device__ __attribute__((noinline)) void stream_direct(const dh_f4 x, float o, 
 {
     float sc[4];
     const uint32_t row = dh_div(v * 4, no);
-    const uint32_t bits = stream_exact<RAW>(x, o, c0, no.d, conf, class_keep, sc);
+    const uint32_t bits = stream_exact<RAW, HALF>(x, o, c0, no.d, conf, class_keep, sc);
     if (!bits) return;
     int at = atomicAdd(count, __popc(bits));
 #pragma unroll
@@ -742,7 +778,7 @@ __device__ __attribute__((noinline)) void stream_direct(const dh_f4 x, float o, 
         }
 }
 
-template <bool RAW, typename T = float>
+template <bool RAW, typename T = float, bool HALF = false>
 __global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(const stream_params P, const float* __restrict__ obj_plane,
                                                               int A, int nc, float conf,
                                                               const unsigned char* __restrict__ class_keep, int cap,
@@ -768,8 +804,9 @@ __global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(
         for (int k = 0; k < DH_MAX_LEVELS; ++k) s_row_first[k] = k < P.nseg ? P.seg[k].row_first : 0;
     }
     __syncthreads();
-    const float conf_pre = RAW ? conf * 0.9999f : conf;              // raw maps: the largest element goes through the sigmoid
-                                                                     // alone; the margin covers any non-monotonic rounding
+    // raw maps: the largest element goes through the sigmoid alone; the margin covers any non-monotonic rounding, and with
+    // the fp16 roundings also a product that rounds up to the threshold (at most 2^-11 of its value)
+    const float conf_pre = RAW ? conf * (HALF ? 0.998f : 0.9999f) : conf;
     // decoded tensor (one segment): a row's objectness is in the compact plane the decode left, or in channel 4 of the row
     const float* __restrict__ plane = (!RAW && obj_plane) ? obj_plane + (size_t)b * A + P.seg[0].row_first : nullptr;
     const float* __restrict__ obj = plane ? plane : P.seg[0].src + (size_t)b * P.seg[0].elems + 4;
@@ -785,7 +822,7 @@ __global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(
             const uint32_t e = (m.y & ((1u << STREAM_SEG_SHIFT) - 1)) * 4, row = dh_div(e, P.no), c0 = e - row * no;
             const uint32_t row_g = s_row_first[m.y >> STREAM_SEG_SHIFT] + row;
             float sc[4];
-            uint32_t bits = stream_exact<RAW>(xv, o, c0, no, conf, class_keep, sc);
+            uint32_t bits = stream_exact<RAW, HALF>(xv, o, c0, no, conf, class_keep, sc);
             if (!live) bits = 0;
             const int cnt = __popc(bits);
             int incl = cnt;
@@ -848,11 +885,11 @@ __global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(
                     const uint32_t (&vi)[STREAM_U]) {
 #pragma unroll
         for (int u = 0; u < STREAM_U; ++u) {
-            const float o = RAW ? dh_sigmoid(oraw[u]) : oraw[u];
+            const float o = RAW ? act_of<HALF>(oraw[u]) : oraw[u];
             const bool has_cls = c0[u] - 2u < no - 2u;              // some channel c0 .. c0+3 lies in [5, no)
             float mx;
             if (RAW) {
-                mx = dh_sigmoid(fmaxf(fmaxf(x[u].x, x[u].y), fmaxf(x[u].z, x[u].w)));
+                mx = act_of<HALF>(fmaxf(fmaxf(x[u].x, x[u].y), fmaxf(x[u].z, x[u].w)));
             } else {                                                // decoded box channels are pixels, far above any score:
                 const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};       // only class channels enter the maximum
                 mx = -INFINITY;
@@ -866,7 +903,7 @@ __global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(
                     qx[w][slot] = x[u];
                     qm[w][slot] = make_uint2(__float_as_uint(o), vi[u]);
                 } else {                                            // queue full: a tile of nothing but candidates on top
-                    stream_direct<RAW>(x[u], o, vi[u] & ((1u << STREAM_SEG_SHIFT) - 1), c0[u], P.no, conf, class_keep,
+                    stream_direct<RAW, HALF>(x[u], o, vi[u] & ((1u << STREAM_SEG_SHIFT) - 1), c0[u], P.no, conf, class_keep,
                                        s_row_first[vi[u] >> STREAM_SEG_SHIFT], nc, &counts[b], cap, out);
                 }                                                   // of what was waiting
             }
@@ -1209,13 +1246,8 @@ __global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, d
         if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;      // a key always names a row of the image: never address beyond it
         float x1, y1, x2, y2;                                                           // general.py:553-560
         if (RAW) {
-            const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
-            const decode_level& L = S.lvl[rr.l];
-            const float x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
-            const float y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
-            const float w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
-            const float h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
-            x1 = x - w / 2; y1 = y - h / 2; x2 = x + w / 2; y2 = y + h / 2;
+            const float4 c = raw_corners<T>(S, b, anchor);
+            x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
         } else {
             const float4 c = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
             x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
@@ -1536,13 +1568,7 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
         const uint32_t cls = ord - anchor * ncd.d;
         if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;      // a key always names a row of the image: never address beyond it
         if (RAW) {
-            const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
-            const decode_level& L = S.lvl[rr.l];
-            const float x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
-            const float y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
-            const float w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
-            const float h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
-            s_box[threadIdx.x] = make_float4(x - w / 2, y - h / 2, x + w / 2, y + h / 2);
+            s_box[threadIdx.x] = raw_corners<T>(S, b, anchor);
         } else {
             s_box[threadIdx.x] = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
         }
@@ -1802,13 +1828,8 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
             if (anchor >= (uint32_t)A) anchor = (uint32_t)A - 1;
             float x1, y1, x2, y2;
             if (RAW) {
-                const raw_row<T> rr = raw_row_of<T>(S, b, (int)anchor);
-                const decode_level& L = S.lvl[rr.l];
-                const float x = decode_box(L, rr.local, 0, dh_sigmoid(ldf(rr.p)));
-                const float y = decode_box(L, rr.local, 1, dh_sigmoid(ldf(rr.p + rr.cs)));
-                const float w = decode_box(L, rr.local, 2, dh_sigmoid(ldf(rr.p + 2 * (size_t)rr.cs)));
-                const float h = decode_box(L, rr.local, 3, dh_sigmoid(ldf(rr.p + 3 * (size_t)rr.cs)));
-                x1 = x - w / 2; y1 = y - h / 2; x2 = x + w / 2; y2 = y + h / 2;
+                const float4 c = raw_corners<T>(S, b, anchor);
+                x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
             } else {
                 const float4 c = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
                 x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
@@ -2332,7 +2353,10 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
         ok = ok && SP.tiles > 0 && SP.tiles < (1u << 30);
         sgx = per_image;
         if (ok) {
-            if (raw && half) hipLaunchKernelGGL((k_nms_prefilter_stream<true, _Float16>), dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane,
+            if (raw && half && S.half_arith)
+                hipLaunchKernelGGL((k_nms_prefilter_stream<true, _Float16, true>), dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane,
+                                   A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
+            else if (raw && half) hipLaunchKernelGGL((k_nms_prefilter_stream<true, _Float16>), dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane,
                                                 A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
             else if (raw) hipLaunchKernelGGL(k_nms_prefilter_stream<true>, dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane, A, nc, conf,
                                              class_keep, cap, keys, L.cap_pad, counts);
@@ -2351,12 +2375,13 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     int dense = (!multi_label && nc + 5 <= 64 * DENSE_REGS / DENSE_ROWS) ? 1 : 0;
     if (dense && !raw && dh_aligned16(S.pred) && ((long long)A * (nc + 5)) % 4 == 0) dense = 2;      // tiles as 16-byte vectors
     const size_t dense_lds = dense ? sizeof(float) * 4 * DENSE_ROWS * (nc + 5) : 0;
-#define DH_PREFILTER(M, N, R, T) hipLaunchKernelGGL((k_nms_prefilter<M, N, R, T>), dim3(gx, bs), dim3(256), (M) ? 0 : dense_lds, st, S, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts, dense)
-#define DH_PREFILTER_N(M, R, T) do { if (nc <= 64) DH_PREFILTER(M, 1, R, T); else if (nc <= 128) DH_PREFILTER(M, 2, R, T); else DH_PREFILTER(M, 0, R, T); } while (0)
+#define DH_PREFILTER(M, N, R, T, H) hipLaunchKernelGGL((k_nms_prefilter<M, N, R, T, H>), dim3(gx, bs), dim3(256), (M) ? 0 : dense_lds, st, S, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts, dense)
+#define DH_PREFILTER_N(M, R, T, H) do { if (nc <= 64) DH_PREFILTER(M, 1, R, T, H); else if (nc <= 128) DH_PREFILTER(M, 2, R, T, H); else DH_PREFILTER(M, 0, R, T, H); } while (0)
     if (streamed) { /* candidates already emitted */ }
-    else if (raw && half) { if (multi_label) DH_PREFILTER_N(true, true, _Float16); else DH_PREFILTER_N(false, true, _Float16); }
-    else if (multi_label) { if (raw) DH_PREFILTER_N(true, true, float); else DH_PREFILTER_N(true, false, float); }
-    else { if (raw) DH_PREFILTER_N(false, true, float); else DH_PREFILTER_N(false, false, float); }
+    else if (raw && half && S.half_arith) { if (multi_label) DH_PREFILTER_N(true, true, _Float16, true); else DH_PREFILTER_N(false, true, _Float16, true); }
+    else if (raw && half) { if (multi_label) DH_PREFILTER_N(true, true, _Float16, false); else DH_PREFILTER_N(false, true, _Float16, false); }
+    else if (multi_label) { if (raw) DH_PREFILTER_N(true, true, float, false); else DH_PREFILTER_N(true, false, float, false); }
+    else { if (raw) DH_PREFILTER_N(false, true, float, false); else DH_PREFILTER_N(false, false, float, false); }
 #undef DH_PREFILTER_N
 #undef DH_PREFILTER
     if (chain) {
@@ -2433,6 +2458,7 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
     S.no = nc + 5;
     S.conv_na = 0;
     S.corners = 0;
+    S.half_arith = 0;
     return nms_run(S, false, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
                    max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
@@ -2448,8 +2474,6 @@ extern "C" int dh_nms_batched(const float* pred, const float* obj_plane, int bs,
 // "obj > conf" keeps what passed, its "obj * cls" returns conf unchanged, and the corners are taken as they are
 // (nms_source::corners).  Thresholds are compared in fp32, as the reference's device kernels compare an fp16 tensor with
 // a Python scalar.
-__device__ __forceinline__ float round_f16(float v) { return (float)(_Float16)v; }
-
 // One thread: VEC consecutive elements of one image.  VEC = 8 (4): one 16-byte (8-byte) load, two (one) 16-byte stores; needs
 // A * no % VEC == 0 and no >= VEC + 4, so that a vector holds channels 0..4 of at most one row (`row`, or `row + 1` when it
 // runs over the row's end).
@@ -2490,7 +2514,7 @@ __global__ void __launch_bounds__(256) k_nms_prepare_f16(const _Float16* __restr
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         const float val = (float)x[k] * (c0 + k >= no ? obj1 : obj0);      // general.py:691 (exact in fp32: 11 x 11 bits)
-        y[k] = wide ? val : round_f16(val);
+        y[k] = wide ? val : dh_round_f16(val);
     }
     if (c0 < 5 || over) {
         const uint32_t r = row + (next ? 1u : 0u);
@@ -2501,9 +2525,9 @@ __global__ void __launch_bounds__(256) k_nms_prepare_f16(const _Float16* __restr
             const int c = k - k0;
             if (c >= 0 && c < 4) {                                          // this element's corner along axis c & 1 (general.py:556-559)
                 const float ctr = (c & 1) ? by : bx, sz = (c & 1) ? bh : bw;
-                const float half_size = wide ? sz / 2 : round_f16(sz / 2);
+                const float half_size = wide ? sz / 2 : dh_round_f16(sz / 2);
                 const float corner = (c & 2) ? ctr + half_size : ctr - half_size;
-                y[k] = wide ? corner : round_f16(corner);
+                y[k] = wide ? corner : dh_round_f16(corner);
             } else if (c == 4) {
                 y[k] = obj > conf ? 1.0f : 0.0f;                            // general.py:656,675
                 if (plane) plane[(size_t)b * (per_image / no) + r] = y[k];
@@ -2577,6 +2601,7 @@ extern "C" int dh_nms_batched_prepared(const float* pred, const float* obj_plane
     S.no = nc + 5;
     S.conv_na = 0;
     S.corners = 1;
+    S.half_arith = 0;
     return nms_run(S, false, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
                    max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
@@ -2688,7 +2713,7 @@ extern "C" int dh_nms_merge(float* out, int* out_span, int bs, int nc, int cap, 
 
 namespace {
 
-int decode_nms_run(const void* const* level_ptrs, bool half, bool conv, const int* ny, const int* nx, int nl, int bs, int na, int no,
+int decode_nms_run(const void* const* level_ptrs, bool half, bool conv, bool half_arith, const int* ny, const int* nx, int nl, int bs, int na, int no,
                    const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
                    int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap, int k_select,
                    float* out, int* out_span, int* cand_count, int* needs_full, void* workspace, size_t workspace_bytes,
@@ -2702,6 +2727,8 @@ int decode_nms_run(const void* const* level_ptrs, bool half, bool conv, const in
     S.no = no;
     S.conv_na = conv ? na : 0;
     S.corners = 0;
+    S.half_arith = half_arith ? 1 : 0;
+    if (half_arith && (!half || conv)) return DH_ERR_ARG;
     uint32_t per_image = 0, rows = 0;
     if (!dh_make_levels(reinterpret_cast<const float* const*>(level_ptrs), ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image,
                         &rows, nullptr))
@@ -2720,7 +2747,7 @@ extern "C" int dh_yolo_decode_nms(const float* const* level_ptrs, const int* ny,
                                   double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
                                   int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
-    return decode_nms_run(reinterpret_cast<const void* const*>(level_ptrs), false, false, ny, nx, nl, bs, na, no, anchor_px, strides,
+    return decode_nms_run(reinterpret_cast<const void* const*>(level_ptrs), false, false, false, ny, nx, nl, bs, na, no, anchor_px, strides,
                           conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out,
                           out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
@@ -2731,8 +2758,19 @@ extern "C" int dh_yolo_decode_nms_f16(const void* const* level_ptrs, const int* 
                                       double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
                                       int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
-    return decode_nms_run(level_ptrs, true, false, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label, agnostic,
-                          class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace,
+    return decode_nms_run(level_ptrs, true, false, false, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label,
+                          agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace,
+                          workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_decode_nms_half(const void* const* level_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                                       const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
+                                       int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
+                                       double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                       int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return decode_nms_run(level_ptrs, true, false, true, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label,
+                          agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace,
                           workspace_bytes, stream);
 }
 
@@ -2742,7 +2780,7 @@ extern "C" int dh_yolo_conv_nms(const float* const* conv_ptrs, const int* ny, co
                                 double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
                                 int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
-    return decode_nms_run(reinterpret_cast<const void* const*>(conv_ptrs), false, true, ny, nx, nl, bs, na, no, anchor_px, strides,
+    return decode_nms_run(reinterpret_cast<const void* const*>(conv_ptrs), false, true, false, ny, nx, nl, bs, na, no, anchor_px, strides,
                           conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out,
                           out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
@@ -2753,7 +2791,7 @@ extern "C" int dh_yolo_conv_nms_f16(const void* const* conv_ptrs, const int* ny,
                                     double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
                                     int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
-    return decode_nms_run(conv_ptrs, true, true, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label,
+    return decode_nms_run(conv_ptrs, true, true, false, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label,
                           agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full,
                           workspace, workspace_bytes, stream);
 }

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .yolo import _anchor_pixels, objectness_plane
+from .yolo import _anchor_pixels, _anchor_pixels_half, objectness_plane
 
 MAX_WH = 7680      # general.py:663
 MAX_NMS = 30000    # general.py:664
@@ -234,14 +234,18 @@ def _class_keep(classes, nc, dev):
 
 
 def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False,
-                      multi_label=False, max_det=300, cap=None, k_select=None, merge=False, conv_na=None):
+                      multi_label=False, max_det=300, cap=None, k_select=None, merge=False, conv_na=None, half_arithmetic=False):
     """nms_launch fed by the raw head maps: the same (rows, meta, cap) as
     nms_launch(detect_decode(levels, anchors, stride), ...), without writing or reading the decoded tensor.
-    conv_na = na: `levels` are the outputs of the head's convolutions, (bs, na*no, ny, nx), instead of the maps."""
+    conv_na = na: `levels` are the outputs of the head's convolutions, (bs, na*no, ny, nx), instead of the maps.
+    half_arithmetic (fp16 maps): the roundings of a half-precision model and of NMS on its fp16 tensor, i.e. the rows of
+    nms_launch(detect_decode(levels, anchors, stride, half_arithmetic=True), ...)."""
     assert 0 <= conf_thres <= 1, f'Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0'
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
     xs, half = L.head_maps(levels)
     nl = len(xs)
+    if half_arithmetic and (conv_na or not half):
+        raise RuntimeError("half_arithmetic needs fp16 head maps (bs, na, ny, nx, no)")
     if conv_na:
         na, bs = int(conv_na), xs[0].shape[0]
         no = xs[0].shape[1] // na
@@ -265,7 +269,7 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
         return None, None, 0
     multi_label = bool(multi_label) and nc > 1
     keep_mask = _class_keep(classes, nc, dev)
-    anchor_px, strides = _anchor_pixels(anchors, stride)
+    anchor_px, strides = _anchor_pixels_half(anchors, stride) if half_arithmetic else _anchor_pixels(anchors, stride)
     lib = L.lib()
     cap = A if cap is None else int(cap)
     rows = torch.empty((bs * max_det, 6), dtype=torch.float32, device=dev)
@@ -273,7 +277,7 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
-    key = ("conv_nms" if conv_na else "detect_nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
+    key = ("conv_nms" if conv_na else ("detect_nms_half" if half_arithmetic else "detect_nms"), bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
     k_select = 0 if merge else _first_attempt(key, max_det, k_select)
     _remember(rows, key, k_select)
     with L.device_guard(dev):
@@ -281,6 +285,8 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
             entry = lib.dh_yolo_conv_nms_f16 if half else lib.dh_yolo_conv_nms
         else:
             entry = lib.dh_yolo_decode_nms_f16 if half else lib.dh_yolo_decode_nms     # fp16 maps are widened on load
+            if half_arithmetic:
+                entry = lib.dh_yolo_decode_nms_half                                    # ... or keep the fp16 roundings
         L.check(entry(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
                       float(conf_thres), float(iou_thres), int(multi_label), int(bool(agnostic)),
                       L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select), L.ptr(rows),
@@ -293,20 +299,24 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
 
 
 def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-               labels=(), max_det=300, merge=False):
+               labels=(), max_det=300, merge=False, half_arithmetic=False):
     """non_max_suppression(Detect(x)[0], ...) (val.py:194,203; detect.py:126,132) straight from the raw head maps
     `levels` (list of (bs,na,ny,nx,5+nc)); anchors / stride as Detect holds them.  Bit-identical to the two-call
     sequence, at about half its HBM traffic: the decoded (bs, A, 5+nc) tensor is neither written nor read.
     labels: a-priori label rows per image (general.py:678-684, the auto-labelling mode of val.py:203).  They join the
-    candidates as rows of the decoded tensor, so with labels the decoded tensor is made and the two-call sequence runs."""
+    candidates as rows of the decoded tensor, so with labels the decoded tensor is made and the two-call sequence runs.
+    half_arithmetic (fp16 maps only): the detections a half-precision model yields (model.half(), val.py:129-130, Detect in
+    place): sigmoid, box, conf = obj * cls and the corners rounded to fp16 where torch rounds them -- bit-identical to
+    non_max_suppression(detect_decode(levels, anchors, stride, half_arithmetic=True), ...).  Without it fp16 maps are
+    widened on load and everything is fp32 arithmetic."""
     if labels is not None and len(labels) and any(len(l) for l in labels):
         from .yolo import detect_decode
-        return non_max_suppression(detect_decode(levels, anchors, stride), conf_thres, iou_thres, classes, agnostic, multi_label,
-                                   labels, max_det, merge)
+        return non_max_suppression(detect_decode(levels, anchors, stride, half_arithmetic=half_arithmetic), conf_thres, iou_thres,
+                                   classes, agnostic, multi_label, labels, max_det, merge)
     cap, k_select = None, None
     while True:
         rows, meta, cap = detect_nms_launch(levels, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
-                                            max_det, cap, k_select, merge)
+                                            max_det, cap, k_select, merge, half_arithmetic=half_arithmetic)
         if rows is None:
             return [torch.zeros((0, 6), device=levels[0].device)] * levels[0].shape[0]
         result, need = nms_finish(rows, meta, cap)

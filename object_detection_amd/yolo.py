@@ -77,18 +77,23 @@ def objectness_logits(maps):
     return _borrow(hit[1], hit[2])
 
 
-def _anchor_pixels(anchors, stride):
+def _anchor_pixels(anchors, stride, half_model=False):
     """Host copies of anchor_grid (= anchors[i] * stride[i], yolo.py:79, formed in fp32 like the reference)
     and of the strides; cached per anchors tensor (the very object, at its version) and stride values, so the
-    steady state does no device-to-host copy."""
+    steady state does no device-to-host copy.  half_model: the anchor_grid of a half-precision model (yolo.py:79-80) --
+    the fp16 anchors buffer times the stride, rounded to fp16, then .float()."""
     svals = tuple(float(v) for v in (stride.tolist() if isinstance(stride, torch.Tensor) else stride))
-    key = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), svals)
+    key = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), svals, bool(half_model))
     hit = _ANCHOR_CACHE.get(key)
     if hit is not None and hit[0]() is anchors:      # same address and version but another tensor: reused storage
         return hit[1]
-    anc = anchors.detach().float().cpu()
     strd = torch.tensor(svals, dtype=torch.float32)
-    made = (L.float_array((anc * strd.view(-1, 1, 1)).reshape(-1).tolist()), L.float_array(strd.tolist()))
+    if half_model:
+        anc = anchors.detach().half().cpu()
+        grid = torch.stack([(anc[l] * torch.tensor(svals[l])).float() for l in range(len(svals))])
+    else:
+        grid = anchors.detach().float().cpu() * strd.view(-1, 1, 1)
+    made = (L.float_array(grid.reshape(-1).tolist()), L.float_array(strd.tolist()))
     if len(_ANCHOR_CACHE) > 64:
         _ANCHOR_CACHE.clear()
     _ANCHOR_CACHE[key] = (weakref.ref(anchors), made)
@@ -131,6 +136,10 @@ def detect_decode(levels, anchors, stride, half_arithmetic=False, inplace=True):
     return out
 
 
+def _anchor_pixels_half(anchors, stride):
+    return _anchor_pixels(anchors, stride, half_model=True)
+
+
 def _detect_decode_half(xs, anchors, stride, inplace=True):
     """yolo.py:56-70 on a half-precision model: fp16 maps in; fp16 decoded tensor out, or fp32 for the torch.cat form
     (dh_yolo_decode_half)."""
@@ -142,15 +151,12 @@ def _detect_decode_half(xs, anchors, stride, inplace=True):
     ny = [int(x.shape[2]) for x in xs]
     nx = [int(x.shape[3]) for x in xs]
     total = sum(na * a * b for a, b in zip(ny, nx))
-    # anchor_grid of such a model (yolo.py:79-80): the fp16 anchors buffer times the stride, rounded to fp16, then .float()
-    svals = [float(v) for v in (stride.tolist() if isinstance(stride, torch.Tensor) else stride)]
-    anc = anchors.detach().half().cpu()
-    anchor_grid = torch.stack([(anc[l] * torch.tensor(svals[l])).float() for l in range(nl)])
+    anchor_grid, svals = _anchor_pixels_half(anchors, stride)
     out = torch.empty((bs, total, no), dtype=torch.float16 if inplace else torch.float32, device=xs[0].device)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
     with L.device_guard(out.device):
         L.check(L.lib().dh_yolo_decode_half(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no,
-                                            L.float_array(anchor_grid.reshape(-1).tolist()), L.float_array(svals), int(bool(inplace)),
+                                            anchor_grid, svals, int(bool(inplace)),
                                             L.ptr(out), None, L.stream()), "dh_yolo_decode_half")
     return out
 

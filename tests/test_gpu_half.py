@@ -150,3 +150,70 @@ def test_half_decode_awkward_shapes_vs_oracle(nc, shapes, inplace):
     got = detect_decode([h.cuda() for h in half], anchors.cuda(), torch.tensor(strides), half_arithmetic=True, inplace=inplace)
     assert got.dtype == want.dtype and got.shape == want.shape
     decoded_half_close(got.cpu().numpy(), want.numpy(), nc + 5, inplace)
+
+
+def _busy_half_head(rs, bs, img, nc):
+    levels = synth_head(rs, bs, img, nc)
+    for x in levels:
+        m = rs.uniform(0, 1, x.shape[:-1]) < 0.01
+        x[m, 4] = rs.normal(1.0, 1.0, int(m.sum()))
+        x[m, 5 + rs.randint(0, nc)] = 2.0
+    return [torch.from_numpy(x).half().cuda() for x in levels]
+
+
+@pytest.mark.parametrize("kw", [dict(conf_thres=0.25, iou_thres=0.45), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+                                dict(conf_thres=0.1, iou_thres=0.5, multi_label=True, max_det=1000),
+                                dict(conf_thres=0.03125, iou_thres=0.5, agnostic=True, max_det=1000),
+                                dict(conf_thres=0.0625, iou_thres=0.3, multi_label=True, classes=[1, 3, 5, 79], max_det=50),
+                                dict(conf_thres=0.25, iou_thres=0.45, merge=True)])
+def test_fused_half_detect_nms_equals_the_two_calls_640(kw):
+    """detect_nms(half_arithmetic=True) on fp16 maps: the rows of non_max_suppression on the fp16 tensor that
+    detect_decode(half_arithmetic=True) makes of them, bit for bit (the two calls are pinned by the reference's fixture
+    and the oracle above) -- and not those of the fp32 arithmetic on the widened maps."""
+    from object_detection_amd.general import detect_nms, non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    rs = np.random.RandomState(17)
+    maps = _busy_half_head(rs, 8, 640, 80)
+    anchors, strides = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    want = non_max_suppression(detect_decode(maps, anchors, strides, half_arithmetic=True), **kw)
+    got = detect_nms(maps, anchors, strides, half_arithmetic=True, **kw)
+    same_lists(got, want)
+    assert sum(w.shape[0] for w in want) > (5 if "classes" in kw or "merge" in kw else 100)
+    wide = detect_nms(maps, anchors, strides, **kw)
+    assert any(a.shape != b.shape or not torch.equal(a, b) for a, b in zip(wide, got))
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fused_half_detect_nms_awkward_shapes(seed):
+    """Row lengths, level shapes and options drawn at random, a-priori labels included (which take the two calls inside)."""
+    from object_detection_amd.general import detect_nms, non_max_suppression
+    from object_detection_amd.yolo import detect_decode
+    rs = np.random.RandomState(7100 + seed)
+    nc = int(rs.choice([1, 2, 3, 7, 11, 27, 80, 130]))
+    nl = int(rs.choice([1, 2, 3]))
+    shapes = [(int(rs.randint(1, 24)), int(rs.randint(1, 24))) for _ in range(nl)]
+    na, bs = int(rs.choice([1, 3])), int(rs.choice([1, 2, 3]))
+    anchors = torch.from_numpy(rs.uniform(1.0, 6.0, (nl, na, 2)).astype(np.float32)).cuda()
+    strides = torch.tensor([8.0 * 2 ** i for i in range(nl)])
+    maps = []
+    for ny, nx in shapes:
+        x = rs.normal(-1.0, 1.5, (bs, na, ny, nx, nc + 5)).astype(np.float32)
+        maps.append(torch.from_numpy(x).half().cuda())
+    kw = dict(conf_thres=float(rs.choice([2.0 ** -10, 0.001, 0.0625, 0.2, 0.25, 0.5])), iou_thres=float(rs.choice([0.0, 0.3, 0.45, 0.6, 1.0])),
+              agnostic=bool(rs.rand() < 0.3), multi_label=bool(rs.rand() < 0.5), max_det=int(rs.choice([1, 5, 300, 1024])))
+    if rs.rand() < 0.3:
+        kw["classes"] = sorted(set(int(c) for c in rs.randint(0, nc, 3)))
+    if rs.rand() < 0.2:
+        kw["labels"] = [torch.from_numpy(np.concatenate([rs.randint(0, nc, (n, 1)), rs.uniform(20, 600, (n, 4))], 1).astype(np.float32))
+                        for n in rs.randint(0, 4, bs)]
+    want = non_max_suppression(detect_decode(maps, anchors, strides, half_arithmetic=True), **kw)
+    got = detect_nms(maps, anchors, strides, half_arithmetic=True, **kw)
+    same_lists(got, want)
+
+
+def test_fused_half_detect_nms_refuses_other_inputs():
+    from object_detection_amd.general import detect_nms
+    anchors, strides = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    maps = [torch.zeros((1, 3, s, s, 85), device="cuda") for s in (8, 4, 2)]
+    with pytest.raises(RuntimeError, match="fp16"):
+        detect_nms(maps, anchors, strides, half_arithmetic=True)
