@@ -205,6 +205,14 @@ int dh_yolo_conv_nms_f16(const void* const* conv_ptrs, const int* ny, const int*
                          int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* dh_yolo_conv_nms_f16 with the arithmetic of a half-precision model, as dh_yolo_decode_nms_half: the detections of
+ * dh_yolo_head_maps_f16 + dh_yolo_decode_half (in-place form) + dh_nms_prepare_f16 + dh_nms_batched_prepared, bit for bit. */
+int dh_yolo_conv_nms_half(const void* const* conv_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                          const float* anchor_px, const float* strides, double conf_thres, double iou_thres, int multi_label,
+                          int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh, int cap,
+                          int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 /* Merge-NMS, the step of non_max_suppression that the reference keeps behind its local switch `merge`
  * (object_detection/yolov5/utils/general.py:668,725-731), applied to the result of the dh_nms_batched /
  * dh_yolo_decode_nms call that has just run with k_select = 0 on the same workspace and stream (same bs, nc, cap, max_nms,

@@ -64,6 +64,9 @@ SIGNATURES = {
     "dh_yolo_conv_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
                                  c_double, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_yolo_conv_nms_half": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
+                                      c_double, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_conv_nms_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_double,
                                      c_double, c_int, c_int, c_void_p, c_int, c_int, c_double, c_int, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -549,7 +549,7 @@ __device__ __forceinline__ void conv_emit(bool pass, u64 key, u64* stage, int* s
     else if (at < cap) out[at] = key;
 }
 
-template <bool MULTI, typename T>
+template <bool MULTI, typename T, bool HALF = false>
 __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, const conv_blocks CB, int nc, float conf,
                                                             const unsigned char* __restrict__ class_keep, int cap,
                                                             u64* __restrict__ keys, int cap_pad, int* __restrict__ counts)
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
     if (threadIdx.x == 0) { s_n = 0; s_valid = CONV_STAGE; }
     __syncthreads();
     float obj = 0.0f;
-    if (s < hw) obj = dh_sigmoid(ldf_nt(plane0 + 4 * (size_t)hw + s));
+    if (s < hw) obj = act_of<HALF>(ldf_nt(plane0 + 4 * (size_t)hw + s));
     const bool cand = s < hw && obj > conf;                           // general.py:656,675
     u64 todo = __ballot(cand);
     float best = -INFINITY;
@@ -587,8 +587,11 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
         // sigmoid; the exact test runs only where some lane of the wave gets past it.
         float bound = -INFINITY;
         if (MULTI && cand) {
-            const float q = conf / obj;                               // < 1 for a candidate
-            if (q > 0.0f && 1.0f - q > 1e-3f) bound = __logf(q / (1.0f - q)) - 0.01f;
+            // < 1 for a candidate.  With the fp16 roundings the sigmoid and the product can each round up by 2^-11 of their
+            // value: the bound is taken for a threshold lowered by more than both (and not at all below 2^-13, where fp16
+            // values are spaced by a fixed amount)
+            const float q = (HALF ? 0.998f : 1.0f) * conf / obj;
+            if (q > 0.0f && 1.0f - q > 1e-3f && !(HALF && conf < 1.3e-4f)) bound = __logf(q / (1.0f - q)) - 0.01f;
         }
         // The class planes are walked CONV_CH at a time, the next group's loads in flight while this one is looked at.  Every
         // lane loads, candidate or not, and a group past the last class re-reads the last plane: loads behind a condition
@@ -607,11 +610,11 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
                 if (MULTI) {
                     if (__ballot(cand && v[u] > bound) == 0) continue;
                     if (class_keep != nullptr && class_keep[c] == 0) continue;                              // general.py:705
-                    const float sc = dh_sigmoid(v[u]) * obj;          // yolo.py:62, general.py:691
+                    const float sc = conf_of<HALF>(act_of<HALF>(v[u]), obj);   // yolo.py:62, general.py:691
                     conv_emit(cand && sc > conf, ((u64)score_key(sc) << 32) | (uint32_t)((row_wave + lane) * nc + c), stage,
                               &s_n, &s_valid, out, &counts[b], cap);  // general.py:698
                 } else {
-                    const float sc = dh_sigmoid(v[u]) * obj;
+                    const float sc = conf_of<HALF>(act_of<HALF>(v[u]), obj);
                     if (cand && sc > best) {                          // general.py:701 (first maximum)
                         best = sc;
                         best_c = c;
@@ -662,7 +665,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter_conv(const nms_source S, 
                     const bool keepc = c < nc && (class_keep == nullptr || class_keep[c] != 0);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float sc = dh_sigmoid(x[k][h]) * o[k];  // yolo.py:62, general.py:691
+                        const float sc = conf_of<HALF>(act_of<HALF>(x[k][h]), o[k]);  // yolo.py:62, general.py:691
                         if (MULTI) {
                             conv_emit(k < nr && keepc && sc > conf,
                                       ((u64)score_key(sc) << 32) | (uint32_t)((row_wave + r[k]) * nc + c), stage, &s_n,
@@ -806,7 +809,8 @@ __global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(
     __syncthreads();
     // raw maps: the largest element goes through the sigmoid alone; the margin covers any non-monotonic rounding, and with
     // the fp16 roundings also a product that rounds up to the threshold (at most 2^-11 of its value)
-    const float conf_pre = RAW ? conf * (HALF ? 0.998f : 0.9999f) : conf;
+    // (and below 2^-14, where fp16 is spaced 2^-24 apart, by half that spacing)
+    const float conf_pre = RAW ? (HALF ? conf * 0.998f - 6.0e-8f : conf * 0.9999f) : conf;
     // decoded tensor (one segment): a row's objectness is in the compact plane the decode left, or in channel 4 of the row
     const float* __restrict__ plane = (!RAW && obj_plane) ? obj_plane + (size_t)b * A + P.seg[0].row_first : nullptr;
     const float* __restrict__ obj = plane ? plane : P.seg[0].src + (size_t)b * P.seg[0].elems + 4;
@@ -2316,9 +2320,10 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
             CB.blocks[l] = (uint32_t)S.conv_na * ((S.lvl[l].plane.d + 255) / 256);
             cgx += CB.blocks[l];
         }
-#define DH_CONV(M, T) hipLaunchKernelGGL((k_nms_prefilter_conv<M, T>), dim3(cgx, bs), dim3(256), 0, st, S, CB, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
-        if (half) { if (multi_label) DH_CONV(true, _Float16); else DH_CONV(false, _Float16); }
-        else { if (multi_label) DH_CONV(true, float); else DH_CONV(false, float); }
+#define DH_CONV(M, T, H) hipLaunchKernelGGL((k_nms_prefilter_conv<M, T, H>), dim3(cgx, bs), dim3(256), 0, st, S, CB, nc, conf, class_keep, cap, keys, L.cap_pad, counts)
+        if (half && S.half_arith) { if (multi_label) DH_CONV(true, _Float16, true); else DH_CONV(false, _Float16, true); }
+        else if (half) { if (multi_label) DH_CONV(true, _Float16, false); else DH_CONV(false, _Float16, false); }
+        else { if (multi_label) DH_CONV(true, float, false); else DH_CONV(false, float, false); }
 #undef DH_CONV
         streamed = true;
     }
@@ -2728,7 +2733,7 @@ int decode_nms_run(const void* const* level_ptrs, bool half, bool conv, bool hal
     S.conv_na = conv ? na : 0;
     S.corners = 0;
     S.half_arith = half_arith ? 1 : 0;
-    if (half_arith && (!half || conv)) return DH_ERR_ARG;
+    if (half_arith && !half) return DH_ERR_ARG;
     uint32_t per_image = 0, rows = 0;
     if (!dh_make_levels(reinterpret_cast<const float* const*>(level_ptrs), ny, nx, nl, na, no, anchor_px, strides, S.lvl, &per_image,
                         &rows, nullptr))
@@ -2792,6 +2797,17 @@ extern "C" int dh_yolo_conv_nms_f16(const void* const* conv_ptrs, const int* ny,
                                     int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
 {
     return decode_nms_run(conv_ptrs, true, true, false, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label,
+                          agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full,
+                          workspace, workspace_bytes, stream);
+}
+
+extern "C" int dh_yolo_conv_nms_half(const void* const* conv_ptrs, const int* ny, const int* nx, int nl, int bs, int na, int no,
+                                     const float* anchor_px, const float* strides, double conf_thres, double iou_thres,
+                                     int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms,
+                                     double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                     int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+{
+    return decode_nms_run(conv_ptrs, true, true, true, ny, nx, nl, bs, na, no, anchor_px, strides, conf_thres, iou_thres, multi_label,
                           agnostic, class_keep, max_det, max_nms, max_wh, cap, k_select, out, out_span, cand_count, needs_full,
                           workspace, workspace_bytes, stream);
 }

@@ -244,8 +244,8 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
     xs, half = L.head_maps(levels)
     nl = len(xs)
-    if half_arithmetic and (conv_na or not half):
-        raise RuntimeError("half_arithmetic needs fp16 head maps (bs, na, ny, nx, no)")
+    if half_arithmetic and not half:
+        raise RuntimeError("half_arithmetic needs fp16 head maps or fp16 convolution outputs")
     if conv_na:
         na, bs = int(conv_na), xs[0].shape[0]
         no = xs[0].shape[1] // na
@@ -277,7 +277,7 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
-    key = ("conv_nms" if conv_na else ("detect_nms_half" if half_arithmetic else "detect_nms"), bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
+    key = (("conv_nms" if conv_na else "detect_nms") + ("_half" if half_arithmetic else ""), bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det)
     k_select = 0 if merge else _first_attempt(key, max_det, k_select)
     _remember(rows, key, k_select)
     with L.device_guard(dev):
@@ -285,8 +285,8 @@ def detect_nms_launch(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, 
             entry = lib.dh_yolo_conv_nms_f16 if half else lib.dh_yolo_conv_nms
         else:
             entry = lib.dh_yolo_decode_nms_f16 if half else lib.dh_yolo_decode_nms     # fp16 maps are widened on load
-            if half_arithmetic:
-                entry = lib.dh_yolo_decode_nms_half                                    # ... or keep the fp16 roundings
+        if half_arithmetic:                                                            # ... or keep the fp16 roundings
+            entry = lib.dh_yolo_conv_nms_half if conv_na else lib.dh_yolo_decode_nms_half
         L.check(entry(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides,
                       float(conf_thres), float(iou_thres), int(multi_label), int(bool(agnostic)),
                       L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select), L.ptr(rows),
@@ -329,20 +329,25 @@ def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes
 
 
 def conv_nms(convs, na, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
-             labels=(), max_det=300, merge=False):
+             labels=(), max_det=300, merge=False, half_arithmetic=False):
     """non_max_suppression(Detect(x)[0], ...) (detect.py:126,132; val.py:194,203 without compute_loss) straight from the
     outputs of Detect's 1x1 convolutions, `convs` = list of (bs, na*no, ny, nx): what Detect.forward holds before the
     layout change of yolo.py:54.  Neither the head maps nor the decoded tensor are written or read; the detections are
     bit-identical to non_max_suppression(head_maps_decode(convs, ...)[0], ...).
-    labels: as for detect_nms (with labels the decoded tensor is made: head_maps_decode, then non_max_suppression)."""
+    labels: as for detect_nms (with labels the decoded tensor is made: head_maps_decode, then non_max_suppression).
+    half_arithmetic (fp16 convolution outputs only): as for detect_nms -- the rows of non_max_suppression on the fp16 tensor a
+    half-precision model decodes in place."""
     if labels is not None and len(labels) and any(len(l) for l in labels):
-        from .yolo import head_maps_decode
-        return non_max_suppression(head_maps_decode(convs, na, anchors, stride, lazy=True)[0], conf_thres, iou_thres, classes,
-                                   agnostic, multi_label, labels, max_det, merge)
+        from .yolo import detect_decode, head_maps, head_maps_decode
+        if half_arithmetic:
+            z = detect_decode(head_maps(convs, na), anchors, stride, half_arithmetic=True)
+        else:
+            z = head_maps_decode(convs, na, anchors, stride, lazy=True)[0]
+        return non_max_suppression(z, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det, merge)
     cap, k_select = None, None
     while True:
         rows, meta, cap = detect_nms_launch(convs, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
-                                            max_det, cap, k_select, merge, conv_na=na)
+                                            max_det, cap, k_select, merge, conv_na=na, half_arithmetic=half_arithmetic)
         if rows is None:
             return [torch.zeros((0, 6), device=convs[0].device)] * convs[0].shape[0]
         result, need = nms_finish(rows, meta, cap)

@@ -328,15 +328,18 @@ class Detect(nn.Module):
                    max_det=300):
         """non_max_suppression(self(x)[0], ...) for callers that want nothing else from the head (detect.py:126-132,
         val.py:194-203 without compute_loss): the convolutions run as in forward, the detections come straight from
-        their outputs; neither the head maps nor the decoded tensor are made.  Same rows as the two calls, bit for bit, for an
-        fp32 head.  For an fp16 head the arithmetic here is fp32 on the widened maps, whereas self(x)[0] followed by
-        non_max_suppression reproduces the reference's fp16 roundings (half_arithmetic): scores agree to fp16 precision,
-        boxes to the fp16 spacing of their coordinates (up to 0.5 px at 640 px), and rows near a threshold can differ."""
-        from .general import conv_nms
+        their outputs; neither the head maps nor the decoded tensor are made.  Same rows as the two calls, bit for bit: for
+        an fp16 head with half_arithmetic (the default) the fp16 roundings of the reference's half-precision model are kept
+        (in-place decode; with inplace=False the two calls run), without it the arithmetic is fp32 on the widened values."""
+        from .general import conv_nms, non_max_suppression
         with torch.no_grad():
+            half = all(v.is_cuda and v.dtype == torch.float16 for v in x) and self.m[0].weight.dtype == torch.float16
+            if half and self.half_arithmetic and not self.inplace:
+                return non_max_suppression(self([v for v in x])[0], conf_thres, iou_thres, classes, agnostic, multi_label, labels,
+                                           max_det)
             convs = [self.m[i](x[i]) for i in range(self.nl)]
             return conv_nms(convs, self.na, self.anchors, self.stride, conf_thres, iou_thres, classes, agnostic, multi_label,
-                            labels, max_det)
+                            labels, max_det, half_arithmetic=half and self.half_arithmetic)
 
     def _make_grid(self, nx=20, ny=20, i=0):
         """yolo.py:72-81: cell indices (x, y) and anchors in pixels, both (1, na, ny, nx, 2).  The decode kernel derives

@@ -163,6 +163,7 @@ def _busy_half_head(rs, bs, img, nc):
 
 @pytest.mark.parametrize("kw", [dict(conf_thres=0.25, iou_thres=0.45), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
                                 dict(conf_thres=0.1, iou_thres=0.5, multi_label=True, max_det=1000),
+                                dict(conf_thres=0.00005, iou_thres=0.6, multi_label=True, max_det=2000),   # below fp16's normal range
                                 dict(conf_thres=0.03125, iou_thres=0.5, agnostic=True, max_det=1000),
                                 dict(conf_thres=0.0625, iou_thres=0.3, multi_label=True, classes=[1, 3, 5, 79], max_det=50),
                                 dict(conf_thres=0.25, iou_thres=0.45, merge=True)])
@@ -217,3 +218,51 @@ def test_fused_half_detect_nms_refuses_other_inputs():
     maps = [torch.zeros((1, 3, s, s, 85), device="cuda") for s in (8, 4, 2)]
     with pytest.raises(RuntimeError, match="fp16"):
         detect_nms(maps, anchors, strides, half_arithmetic=True)
+
+
+@pytest.mark.parametrize("kw", [dict(conf_thres=0.25, iou_thres=0.45), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+                                dict(conf_thres=0.00005, iou_thres=0.6, multi_label=True, max_det=2000),
+                                dict(conf_thres=0.03125, iou_thres=0.5, agnostic=True, max_det=1000),
+                                dict(conf_thres=0.0625, iou_thres=0.3, multi_label=True, classes=[1, 3, 5, 79], max_det=50)])
+def test_fused_half_conv_nms_equals_the_two_calls(kw):
+    """conv_nms(half_arithmetic=True) on the fp16 outputs of the head's convolutions: the rows of non_max_suppression on the
+    fp16 tensor a half-precision model decodes from them (both candidate searches of the convolution layout: wave by wave at
+    the inference threshold, position-parallel with the logit-space bound at the validation thresholds, one of them below the
+    spacing of small fp16 values)."""
+    from object_detection_amd.general import conv_nms, non_max_suppression
+    from object_detection_amd.yolo import detect_decode, head_maps
+    rs = np.random.RandomState(23)
+    maps = _busy_half_head(rs, 4, 640, 80)
+    convs = [m.permute(0, 1, 4, 2, 3).reshape(m.shape[0], -1, m.shape[2], m.shape[3]).contiguous() for m in maps]
+    anchors, strides = oy.grid_anchors().cuda(), torch.tensor(oy.YOLOV5S_STRIDES)
+    for a, b in zip(head_maps(convs, 3), maps):
+        assert torch.equal(a, b)
+    want = non_max_suppression(detect_decode(maps, anchors, strides, half_arithmetic=True), **kw)
+    got = conv_nms(convs, 3, anchors, strides, half_arithmetic=True, **kw)
+    same_lists(got, want)
+    assert sum(w.shape[0] for w in want) > 5
+
+
+@pytest.mark.parametrize("inplace", [True, False])
+def test_half_detect_module_detections_equal_forward_plus_nms(inplace):
+    """Detect.detections on a half-precision head: the rows of non_max_suppression(det(x)[0]), the reference's sequence,
+    bit for bit -- fused for the in-place decode, through the two calls for the torch.cat form."""
+    from object_detection_amd.general import non_max_suppression
+    from object_detection_amd.yolo import Detect
+    torch.manual_seed(3)
+    det = Detect(nc=12, anchors=oy.YOLOV5S_ANCHORS_PX, ch=(8, 16, 32), inplace=inplace).cuda().eval()
+    det.stride = torch.tensor(oy.YOLOV5S_STRIDES)
+    det.anchors /= det.stride.view(-1, 1, 1).cuda()
+    with torch.no_grad():
+        for m in det.m:
+            m.bias.view(3, -1)[:, 4] += 1.0
+    det = det.half()
+    feats = [torch.randn(3, c, 96 // s, 128 // s, device="cuda").half() for c, s in zip((8, 16, 32), (8, 16, 32))]
+    for kw in (dict(), dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)):
+        with torch.no_grad():
+            z = det([f.clone() for f in feats])[0]
+            assert z.dtype == (torch.float16 if inplace else torch.float32)
+            want = non_max_suppression(z, **kw)
+        got = det.detections([f.clone() for f in feats], **kw)
+        same_lists(got, want)
+        assert sum(int(w.shape[0]) for w in want) > 0
