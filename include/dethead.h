@@ -160,6 +160,16 @@ int dh_nms_batched_prepared(const float* pred, const float* obj_plane, int bs, i
                             int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* dh_nms_batched on the fp16 decoded tensor of a half-precision model (non_max_suppression behind model.half(),
+ * object_detection/yolov5/val.py:129-130,203) without the fp32 copy of dh_nms_prepare_f16: conf = obj * cls rounded to
+ * fp16 (utils/general.py:691) and the corners formed in fp16 (general.py:694,553-560) as the rows are looked at; same rows
+ * as dh_nms_prepare_f16 + dh_nms_batched_prepared, bit for bit.  obj_plane: optional fp32 copy of channel 4, (bs, A).
+ * Images with apriori labels (general.py:678-684) are widened before that arithmetic and need the prepared form. */
+int dh_nms_batched_f16(const void* pred_f16, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
+                       int multi_label, int agnostic, const unsigned char* class_keep, int max_det, int max_nms, double max_wh,
+                       int cap, int k_select, float* out, int* out_span, int* cand_count, int* needs_full, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* Fused inference path: the NMS of dh_nms_batched fed directly by the raw head maps of dh_yolo_decode (same level
  * description), i.e. non_max_suppression(Detect(x)[0]) of object_detection/yolov5/val.py:194,203 and detect.py:126,132
  * without materialising the decoded (bs, A, no) tensor: candidate rows are decoded on the fly with the arithmetic of

@@ -81,16 +81,9 @@ struct nms_source {
     int conv_na;     // 0: lvl[].src are head maps (bs, na, ny, nx, no); na > 0: they are the outputs of the head's 1x1
                      // convolutions, (bs, na*no, ny, nx), where channel c of a row sits ny*nx elements after channel c - 1
     int corners;     // pred rows hold the corners x1, y1, x2, y2 already (k_nms_prepare_f16), not centre and size
-    int half_arith;  // fp16 raw maps only: the roundings of a half-precision model and of NMS on its fp16 tensor (below)
+    int half_arith;  // fp16 sources only: the roundings of a half-precision model and of NMS on its fp16 tensor (below); with
+                     // nl == 0, pred is then the fp16 decoded tensor itself (a pointer in disguise, like decode_level::src)
 };
-
-// channels 0..3 of a row of the decoded tensor as corners (general.py:553-560)
-__device__ __forceinline__ float4 pred_corners(const nms_source& S, const float* __restrict__ p)
-{
-    const float x = p[0], y = p[1], w = p[2], h = p[3];
-    if (S.corners) return make_float4(x, y, w, h);
-    return make_float4(x - w / 2, y - h / 2, x + w / 2, y + h / 2);
-}
 
 // The raw maps hold fp32 or fp16 elements (T = float or _Float16; decode_level::src is then a pointer in disguise).
 // fp16 values are widened to fp32 on load and everything after that is the fp32 arithmetic, so a half-precision head
@@ -110,6 +103,21 @@ __device__ __forceinline__ dh_f4 ld4_nt(const _Float16* p, uint32_t v)
     const dh_h4 h = __builtin_nontemporal_load(reinterpret_cast<const dh_h4*>(p) + v);
     const dh_f4 f = {(float)h.x, (float)h.y, (float)h.z, (float)h.w};
     return f;
+}
+
+// channels 0..3 of row `anchor` of image b of the decoded tensor as corners (general.py:553-560); on the fp16 tensor of a
+// half-precision model they are formed in fp16, like everything before the detection matrix is assembled (general.py:694)
+template <typename T>
+__device__ __forceinline__ float4 pred_corners(const nms_source& S, int b, int A, uint32_t anchor, int no)
+{
+    const T* __restrict__ p = reinterpret_cast<const T*>(S.pred) + ((size_t)b * A + anchor) * no;
+    const float x = ldf(p), y = ldf(p + 1), w = ldf(p + 2), h = ldf(p + 3);
+    if (S.corners) return make_float4(x, y, w, h);
+    if (sizeof(T) == 2) {
+        const float hw = dh_round_f16(w / 2), hh = dh_round_f16(h / 2);
+        return make_float4(dh_round_f16(x - hw), dh_round_f16(y - hh), dh_round_f16(x + hw), dh_round_f16(y + hh));
+    }
+    return make_float4(x - w / 2, y - h / 2, x + w / 2, y + h / 2);
 }
 
 template <typename T>
@@ -220,7 +228,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int no = nc + 5;
-    const float* __restrict__ img = RAW ? nullptr : S.pred + (size_t)b * A * no;
+    const T* __restrict__ img = RAW ? nullptr : reinterpret_cast<const T*>(S.pred) + (size_t)b * A * no;
     u64* __restrict__ out = keys + (size_t)b * cap_pad;
     __shared__ u64 stage[4][STAGE_KEYS];
     extern __shared__ __align__(16) float s_dense[];   // single-label, dense != 0: 4 waves x DENSE_ROWS rows x no floats
@@ -239,7 +247,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
         if (row < A) {
             // the strided column is touched once: non-temporal loads fetch single 64-byte sectors (2.2x faster cold)
             if (RAW) obj = act_of<HALF>(ldf_nt(raw_row_of<T>(S, b, row).p + 4));
-            else obj = obj_plane ? obj_plane[(size_t)b * A + row] : __builtin_nontemporal_load(img + (size_t)row * no + 4);
+            else obj = obj_plane ? obj_plane[(size_t)b * A + row] : ldf_nt(img + (size_t)row * no + 4);
         }
         const bool cand = (row < A) && (obj > conf);                       // general.py:656,675
         u64 todo = __ballot(cand);
@@ -259,7 +267,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
             if (!RAW && sizeof(T) == 4 && dense == 2) {
                 const int full = min(64 / DENSE_ROWS, (A - row0) / DENSE_ROWS);     // wave-uniform
                 const int nv = DENSE_ROWS / 4 * no;                                  // vectors per tile
-                const dh_f4* __restrict__ rows4 = reinterpret_cast<const dh_f4*>(img + (size_t)row0 * no);
+                const dh_f4* __restrict__ rows4 = reinterpret_cast<const dh_f4*>(reinterpret_cast<const float*>(S.pred) + ((size_t)b * A + row0) * no);
                 dh_f4 buf[2][DENSE_VREGS];
                 if (full > 0) {
 #pragma unroll
@@ -282,7 +290,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
                     const float* __restrict__ rowp = tile + rr * no + 5;
 #pragma unroll 4
                     for (int c = part; c < nc; c += 4) {
-                        const float sc = rowp[c] * myo;                                         // general.py:691
+                        const float sc = conf_of<HALF>(rowp[c], myo);                           // general.py:691
                         if (sc > qv) { qv = sc; qc = c; }
                     }
 #pragma unroll
@@ -304,7 +312,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
                 if (rs >= A) break;
                 if (((todo >> (DENSE_ROWS * sub)) & ((1ull << DENSE_ROWS) - 1ull)) == 0) continue;
                 const int n_el = min(DENSE_ROWS, A - rs) * no;
-                const T* __restrict__ base = RAW ? raw_row_of<T>(S, b, rs).p : reinterpret_cast<const T*>(img + (size_t)rs * no);
+                const T* __restrict__ base = RAW ? raw_row_of<T>(S, b, rs).p : img + (size_t)rs * no;
                 float reg[DENSE_REGS];
 #pragma unroll
                 for (int i = 0; i < DENSE_REGS; ++i) reg[i] = (i * 64 + lane < n_el) ? ldf(base + i * 64 + lane) : 0.0f;
@@ -319,7 +327,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
                 if (rr * no < n_el) {
                     const float* __restrict__ rowp = tile + rr * no + 5;
                     for (int c = part; c < nc; c += 4) {
-                        const float sc = RAW ? conf_of<HALF>(act_of<HALF>(rowp[c]), myo) : rowp[c] * myo;   // yolo.py:62, general.py:691
+                        const float sc = conf_of<HALF>(RAW ? act_of<HALF>(rowp[c]) : rowp[c], myo);   // yolo.py:62, general.py:691
                         if (sc > qv) { qv = sc; qc = c; }
                     }
                 }
@@ -360,7 +368,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
                 const int myr = q == 0 ? r[0] : (q == 1 ? r[1] : (q == 2 ? r[2] : r[3]));
                 const float myo = q == 0 ? o[0] : (q == 1 ? o[1] : (q == 2 ? o[2] : o[3]));
                 const T* qp = (RAW ? raw_row_of<T>(S, b, row0 + myr).p
-                                   : reinterpret_cast<const T*>(img + (size_t)(row0 + myr) * no)) + 5;
+                                   : img + (size_t)(row0 + myr) * no) + 5;
                 float qv = -INFINITY;
                 int qc = 0x7fffffff;
                 if (NCH > 0) {
@@ -370,13 +378,13 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
 #pragma unroll
                     for (int h = 0; h < NCH * 4; ++h) {
                         const int c = h * 16 + j;
-                        const float sc = RAW ? conf_of<HALF>(act_of<HALF>(pre16[h]), myo) : pre16[h] * myo;   // yolo.py:62, general.py:691
+                        const float sc = conf_of<HALF>(RAW ? act_of<HALF>(pre16[h]) : pre16[h], myo);   // yolo.py:62, general.py:691
                         if (c < nc && sc > qv) { qv = sc; qc = c; }
                     }
                 } else {
                     for (int c = j; c < nc; c += 16) {
                         const float x = ldf(qp + c);
-                        const float sc = RAW ? conf_of<HALF>(act_of<HALF>(x), myo) : x * myo;
+                        const float sc = conf_of<HALF>(RAW ? act_of<HALF>(x) : x, myo);
                         if (sc > qv) { qv = sc; qc = c; }
                     }
                 }
@@ -401,7 +409,7 @@ __global__ void __launch_bounds__(256) k_nms_prefilter(const nms_source S, const
             for (int k = 0; k < 4; ++k) {
                 bv[k] = -INFINITY;
                 bc[k] = 0x7fffffff;
-                rp[k] = (RAW ? raw_row_of<T>(S, b, row0 + r[k]).p : reinterpret_cast<const T*>(img + (size_t)(row0 + r[k]) * no)) + 5;
+                rp[k] = (RAW ? raw_row_of<T>(S, b, row0 + r[k]).p : img + (size_t)(row0 + r[k]) * no) + 5;
             }
             float pre[4][NCH > 0 ? NCH : 1];
             if (NCH > 0) {
@@ -753,7 +761,7 @@ __device__ __forceinline__ uint32_t stream_exact(const dh_f4 x, float o, uint32_
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t c = c0 + k - 5u;                              // class, if the channel is in [5, no)
-        sc[k] = RAW ? conf_of<HALF>(act_of<HALF>(xs[k]), o) : xs[k] * o;   // yolo.py:62, general.py:691
+        sc[k] = conf_of<HALF>(RAW ? act_of<HALF>(xs[k]) : xs[k], o);       // yolo.py:62, general.py:691
         bool ok = c < no - 5u && sc[k] > conf;                       // general.py:698
         if (class_keep != nullptr && ok) ok = class_keep[c] != 0;    // general.py:705-706
         bits |= ok ? 1u << k : 0u;
@@ -810,11 +818,10 @@ __global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(
     // raw maps: the largest element goes through the sigmoid alone; the margin covers any non-monotonic rounding, and with
     // the fp16 roundings also a product that rounds up to the threshold (at most 2^-11 of its value)
     // (and below 2^-14, where fp16 is spaced 2^-24 apart, by half that spacing)
-    const float conf_pre = RAW ? (HALF ? conf * 0.998f - 6.0e-8f : conf * 0.9999f) : conf;
+    const float conf_pre = HALF ? conf * 0.998f - 6.0e-8f : (RAW ? conf * 0.9999f : conf);
     // decoded tensor (one segment): a row's objectness is in the compact plane the decode left, or in channel 4 of the row
     const float* __restrict__ plane = (!RAW && obj_plane) ? obj_plane + (size_t)b * A + P.seg[0].row_first : nullptr;
-    const float* __restrict__ obj = plane ? plane : P.seg[0].src + (size_t)b * P.seg[0].elems + 4;
-    const uint32_t obj_stride = plane ? 1u : no;
+    const T* __restrict__ column = reinterpret_cast<const T*>(P.seg[0].src) + (size_t)b * P.seg[0].elems + 4;
     // tests the n vectors the wave has set aside (all 64 lanes call this together)
     auto drain = [&](int n) {
         for (int base = 0; base < n; base += 64) {
@@ -881,7 +888,7 @@ __global__ void __launch_bounds__(256, STREAM_WG_PER_CU) k_nms_prefilter_stream(
             c0[u] = live ? e - row * no : no;                       // c0 = no: a dead vector has no class channel
             x[u] = ld4_nt(src, vv);
             if constexpr (RAW) oraw[u] = ldf(src + (size_t)row * no + 4);
-            else oraw[u] = obj[(size_t)row * obj_stride];
+            else oraw[u] = plane ? plane[row] : ldf(column + (size_t)row * no);
         }
     };
     // one tile's vectors: set aside those that may hold a candidate
@@ -1253,7 +1260,7 @@ __global__ void __launch_bounds__(256) k_nms_gather(const nms_source S, int A, d
             const float4 c = raw_corners<T>(S, b, anchor);
             x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
         } else {
-            const float4 c = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
+            const float4 c = pred_corners<T>(S, b, A, anchor, no);
             x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
         }
         float* __restrict__ d = det + ((size_t)b * m_cap + r) * 6;
@@ -1574,7 +1581,7 @@ __global__ void __launch_bounds__(1024) k_nms_small(const nms_source S, int A, d
         if (RAW) {
             s_box[threadIdx.x] = raw_corners<T>(S, b, anchor);
         } else {
-            s_box[threadIdx.x] = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
+            s_box[threadIdx.x] = pred_corners<T>(S, b, A, anchor, no);
         }
         s_off[threadIdx.x] = agnostic ? 0.0f : (float)cls * max_wh;                      // general.py:720
     }
@@ -1835,7 +1842,7 @@ __global__ void __launch_bounds__(1024) k_nms_groups(const nms_source S, int A, 
                 const float4 c = raw_corners<T>(S, b, anchor);
                 x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
             } else {
-                const float4 c = pred_corners(S, S.pred + ((size_t)b * A + anchor) * no);
+                const float4 c = pred_corners<T>(S, b, A, anchor, no);
                 x1 = c.x; y1 = c.y; x2 = c.z; y2 = c.w;
             }
             s_box[i] = make_float4(x1, y1, x2, y2);
@@ -2365,6 +2372,8 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
                                                 A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
             else if (raw) hipLaunchKernelGGL(k_nms_prefilter_stream<true>, dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane, A, nc, conf,
                                              class_keep, cap, keys, L.cap_pad, counts);
+            else if (half) hipLaunchKernelGGL((k_nms_prefilter_stream<false, _Float16, true>), dim3(sgx, bs), dim3(256), 0, st, SP,
+                                              obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts);
             else hipLaunchKernelGGL(k_nms_prefilter_stream<false>, dim3(sgx, bs), dim3(256), 0, st, SP, obj_plane, A, nc, conf,
                                     class_keep, cap, keys, L.cap_pad, counts);
             streamed = true;
@@ -2378,13 +2387,14 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     }
     // dense single-label path: 4 waves x DENSE_ROWS rows x no floats of LDS, when a tile fits the per-lane registers
     int dense = (!multi_label && nc + 5 <= 64 * DENSE_REGS / DENSE_ROWS) ? 1 : 0;
-    if (dense && !raw && dh_aligned16(S.pred) && ((long long)A * (nc + 5)) % 4 == 0) dense = 2;      // tiles as 16-byte vectors
+    if (dense && !raw && !half && dh_aligned16(S.pred) && ((long long)A * (nc + 5)) % 4 == 0) dense = 2;      // tiles as 16-byte vectors
     const size_t dense_lds = dense ? sizeof(float) * 4 * DENSE_ROWS * (nc + 5) : 0;
 #define DH_PREFILTER(M, N, R, T, H) hipLaunchKernelGGL((k_nms_prefilter<M, N, R, T, H>), dim3(gx, bs), dim3(256), (M) ? 0 : dense_lds, st, S, obj_plane, A, nc, conf, class_keep, cap, keys, L.cap_pad, counts, dense)
 #define DH_PREFILTER_N(M, R, T, H) do { if (nc <= 64) DH_PREFILTER(M, 1, R, T, H); else if (nc <= 128) DH_PREFILTER(M, 2, R, T, H); else DH_PREFILTER(M, 0, R, T, H); } while (0)
     if (streamed) { /* candidates already emitted */ }
     else if (raw && half && S.half_arith) { if (multi_label) DH_PREFILTER_N(true, true, _Float16, true); else DH_PREFILTER_N(false, true, _Float16, true); }
     else if (raw && half) { if (multi_label) DH_PREFILTER_N(true, true, _Float16, false); else DH_PREFILTER_N(false, true, _Float16, false); }
+    else if (half) { if (multi_label) DH_PREFILTER_N(true, false, _Float16, true); else DH_PREFILTER_N(false, false, _Float16, true); }
     else if (multi_label) { if (raw) DH_PREFILTER_N(true, true, float, false); else DH_PREFILTER_N(true, false, float, false); }
     else { if (raw) DH_PREFILTER_N(false, true, float, false); else DH_PREFILTER_N(false, false, float, false); }
 #undef DH_PREFILTER_N
@@ -2397,7 +2407,8 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
         int* kept_count = m_arr;                                        // zero after the fill above
         int* left_flag = (int*)(ws + L.off_flag);
 #define DH_GROUPS(R, T) hipLaunchKernelGGL((k_nms_groups<R, T>), dim3(G, bs), dim3(1024), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad, counts, cap, max_nms, (float)max_wh, thr, max_det, det, L.m_cap, kept_count, truncated, left_flag)
-        if (raw && half) DH_GROUPS(true, _Float16); else if (raw) DH_GROUPS(true, float); else DH_GROUPS(false, float);
+        if (raw && half) DH_GROUPS(true, _Float16); else if (raw) DH_GROUPS(true, float); else if (half) DH_GROUPS(false, _Float16);
+        else DH_GROUPS(false, float);
 #undef DH_GROUPS
         hipLaunchKernelGGL(k_nms_groups_final, dim3(bs), dim3(1024), 0, st, dh_make_fastdiv((uint32_t)nc), det, L.m_cap, counts, kept_count,
                            truncated, left_flag, max_det, out, cursor, (int2*)out_span, cand_count, needs_full, bs * max_det);
@@ -2407,7 +2418,8 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
         if (max_det > SMALL_MAX) return DH_ERR_ARG;
         const float off = agnostic ? 0.0f : (float)max_wh;
 #define DH_SMALL(R, T) hipLaunchKernelGGL((k_nms_small<R, T>), dim3(bs), dim3(1024), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), keys, L.cap_pad, counts, cap, agnostic, off, thr, max_det, out, cursor, (int2*)out_span, cand_count, needs_full, bs * max_det)
-        if (raw && half) DH_SMALL(true, _Float16); else if (raw) DH_SMALL(true, float); else DH_SMALL(false, float);
+        if (raw && half) DH_SMALL(true, _Float16); else if (raw) DH_SMALL(true, float); else if (half) DH_SMALL(false, _Float16);
+        else DH_SMALL(false, float);
 #undef DH_SMALL
         return dh_launch_status();
     }
@@ -2431,6 +2443,9 @@ int nms_run(const nms_source& S, bool raw, bool half, const float* obj_plane, in
     else if (raw)
         hipLaunchKernelGGL(k_nms_gather<true>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), ranked, ranked_pad,
                            m_arr, det, keys2, L.m_pad, L.m_cap, range);
+    else if (half)
+        hipLaunchKernelGGL((k_nms_gather<false, _Float16>), ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), ranked,
+                           ranked_pad, m_arr, det, keys2, L.m_pad, L.m_cap, range);
     else
         hipLaunchKernelGGL(k_nms_gather<false>, ggrid, dim3(256), 0, st, S, A, dh_make_fastdiv((uint32_t)nc), ranked, ranked_pad,
                            m_arr, det, keys2, L.m_pad, L.m_cap, range);
@@ -2608,6 +2623,27 @@ extern "C" int dh_nms_batched_prepared(const float* pred, const float* obj_plane
     S.corners = 1;
     S.half_arith = 0;
     return nms_run(S, false, false, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
+                   max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
+}
+
+// non_max_suppression on the fp16 decoded tensor itself: the rows of dh_nms_prepare_f16 + dh_nms_batched_prepared without the
+// fp32 copy -- conf = obj * cls is rounded to fp16 where the candidates are looked for, the corners are formed in fp16 where
+// the boxes are fetched.  Not for images with apriori labels (they are widened before that arithmetic: the prepared form).
+extern "C" int dh_nms_batched_f16(const void* pred_f16, const float* obj_plane, int bs, int A, int nc, double conf_thres, double iou_thres,
+                                  int multi_label, int agnostic, const unsigned char* class_keep, int max_det,
+                                  int max_nms, double max_wh, int cap, int k_select, float* out, int* out_span, int* cand_count,
+                                  int* needs_full, void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (bs > 0 && !pred_f16) return DH_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(pred_f16) & 1u) return DH_ERR_ALIGN;
+    nms_source S;
+    S.pred = reinterpret_cast<const float*>(pred_f16);
+    S.nl = 0;
+    S.no = nc + 5;
+    S.conv_na = 0;
+    S.corners = 0;
+    S.half_arith = 1;
+    return nms_run(S, false, true, obj_plane, bs, A, nc, conf_thres, iou_thres, multi_label, agnostic, class_keep, max_det, max_nms,
                    max_wh, cap, k_select, out, out_span, cand_count, needs_full, workspace, workspace_bytes, stream);
 }
 

@@ -171,12 +171,17 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     assert 0 <= iou_thres <= 1, f'Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0'
     if isinstance(prediction, torch.Tensor) and (prediction.dim() != 3 or prediction.shape[2] < 6):
         raise RuntimeError(f"prediction must be (bs, A, 5+nc) with nc >= 1, got {tuple(prediction.shape)}")
-    # an fp16 tensor gets the reference's fp16 arithmetic (see _prepared_from_half); anything else is computed in fp32
-    prepared = isinstance(prediction, torch.Tensor) and prediction.is_cuda and prediction.dtype == torch.float16 \
+    # an fp16 tensor gets the reference's fp16 arithmetic: where the rows are looked at (dh_nms_batched_f16), or, when some
+    # image has apriori labels and is therefore widened first, in a pass of its own (see _prepared_from_half); anything else
+    # is computed in fp32
+    half = isinstance(prediction, torch.Tensor) and prediction.is_cuda and prediction.dtype == torch.float16 \
         and prediction.numel() > 0
+    prepared = half and bool(labels) and len(labels) > 0
     plane = None
     if prepared:
         pred, plane = _prepared_from_half(prediction, conf_thres, labels)
+    elif half:
+        pred = prediction.contiguous()
     else:
         pred = L.dev_f32(prediction, "prediction").contiguous()
     bs, _, no = pred.shape
@@ -199,7 +204,7 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     meta = torch.empty(4 * bs, dtype=torch.int32, device=dev)
     ws_bytes = lib.dh_nms_workspace(bs, nc, cap, MAX_NMS)
     ws = L.workspace(ws_bytes, dev)
-    key = ("nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det, prepared)
+    key = ("nms", bs, A, nc, float(conf_thres), float(iou_thres), multi_label, bool(agnostic), keep_mask is None, max_det, prepared, half)
     k_select = 0 if merge else _first_attempt(key, max_det, k_select)
     _remember(rows, key, k_select)
     tail = (int(multi_label), int(bool(agnostic)), L.ptr(keep_mask), max_det, MAX_NMS, float(MAX_WH), cap, int(k_select),
@@ -209,6 +214,9 @@ def nms_launch(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
         if prepared:
             L.check(lib.dh_nms_batched_prepared(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), *tail),
                     "dh_nms_batched_prepared")
+        elif half:
+            L.check(lib.dh_nms_batched_f16(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), *tail),
+                    "dh_nms_batched_f16")
         else:
             L.check(lib.dh_nms_batched(L.ptr(pred), L.ptr(plane), bs, A, nc, float(conf_thres), float(iou_thres), *tail),
                     "dh_nms_batched")

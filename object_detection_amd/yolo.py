@@ -153,11 +153,17 @@ def _detect_decode_half(xs, anchors, stride, inplace=True):
     total = sum(na * a * b for a, b in zip(ny, nx))
     anchor_grid, svals = _anchor_pixels_half(anchors, stride)
     out = torch.empty((bs, total, no), dtype=torch.float16 if inplace else torch.float32, device=xs[0].device)
+    # the objectness column once more, compact and widened (exact): non_max_suppression on `out` reads it instead of the
+    # strided column, as it does behind the fp32 decode
+    plane = torch.empty((bs, total), dtype=torch.float32, device=xs[0].device) if _USE_PLANES else None
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in xs])
     with L.device_guard(out.device):
+        made_on = L.raw_stream()
         L.check(L.lib().dh_yolo_decode_half(ptrs, L.int_array(ny), L.int_array(nx), nl, bs, na, no,
                                             anchor_grid, svals, int(bool(inplace)),
-                                            L.ptr(out), None, L.stream()), "dh_yolo_decode_half")
+                                            L.ptr(out), L.ptr(plane), L.c_void_p(made_on)), "dh_yolo_decode_half")
+    if plane is not None:
+        _remember_planes(out, None, plane, None, made_on)
     return out
 
 
@@ -173,7 +179,8 @@ def _remember_planes(out, xs, plane, logits, made_on):
             registry.clear()
     in_capture = torch.cuda.is_current_stream_capturing()
     _OBJ_PLANES[out.data_ptr()] = (weakref.ref(out), out._version, plane, made_on, in_capture)
-    _LOGIT_PLANES[xs[0].data_ptr()] = ([(weakref.ref(x), x._version, tuple(x.shape)) for x in xs], logits, made_on, in_capture)
+    if logits is not None:
+        _LOGIT_PLANES[xs[0].data_ptr()] = ([(weakref.ref(x), x._version, tuple(x.shape)) for x in xs], logits, made_on, in_capture)
 
 
 def _head_geometry(convs, na):
