@@ -102,6 +102,14 @@ int dh_yolo_head_maps(const float* const* conv_ptrs, float* const* map_ptrs, con
 int dh_yolo_head_maps_f16(const void* const* conv_ptrs, void* const* map_ptrs, const int* ny, const int* nx, int nl, int bs,
                           int na, int no, const float* anchor_px, const float* strides, float* out, float* obj_plane,
                           float* obj_logit_plane, void* stream);
+
+/* The same for a half-precision model (model.half(), object_detection/yolov5/val.py:129-130): fp16 convolution outputs in,
+ * fp16 maps (optional) and the fp16 decoded tensor of dh_yolo_decode_half (in-place form, yolo.py:59-61, same roundings)
+ * out, in one launch.  anchor_px as for dh_yolo_decode_half; obj_plane (optional): channel 4 of the decoded tensor,
+ * widened, (bs, A). */
+int dh_yolo_head_maps_half(const void* const* conv_ptrs, void* const* map_ptrs, const int* ny, const int* nx, int nl, int bs,
+                           int na, int no, const float* anchor_px, const float* strides, void* out_f16, float* obj_plane,
+                           void* stream);
 /* Backward of that layout change (what autograd does for the permute + contiguous of yolo.py:54, followed by the
  * contiguous copy the convolution's backward asks for): grad_map_ptrs[l] (bs, na, ny, nx, no) contiguous ->
  * grad_conv_ptrs[l] (bs, na*no, ny, nx) contiguous. */

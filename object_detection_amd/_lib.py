@@ -42,6 +42,8 @@ SIGNATURES = {
     "dh_yolo_head_maps_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dh_yolo_head_maps_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dh_yolo_head_maps_half": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
     "dh_yolo_head_maps_bwd_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dh_nms_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
     "dh_nms_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int, c_int, c_void_p, c_int, c_int,

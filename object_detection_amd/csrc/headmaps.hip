@@ -15,7 +15,8 @@
 // stores; the decode arithmetic sits between that read and the stores and is the arithmetic of k_yolo_decode.
 // A half-precision head (model.half(), object_detection/yolov5/val.py:115,129) keeps fp16 convolution outputs and fp16
 // maps: every lane then carries two positions per load (S = 128), the tile is held in fp16, and the decode widens to
-// fp32 exactly as dh_yolo_decode_f16 does.
+// fp32 exactly as dh_yolo_decode_f16 does -- or (HALF) keeps the roundings of such a model's own in-place decode and
+// writes the fp16 tensor of dh_yolo_decode_half.
 #include "dh_common.h"
 #include "dh_decode.h"
 #include "../../include/dethead.h"
@@ -38,7 +39,7 @@ struct head_params {
     dh_fastdiv no;
     uint32_t per_image;
     uint32_t rows_per_image;
-    float* out;           // decoded (bs, A, no), or null: layout change only
+    float* out;           // decoded (bs, A, no), or null: layout change only (HALF: an fp16 tensor under the same pointer type)
     float* obj_plane;     // as in dh_yolo_decode
     float* logit_plane;
 };
@@ -119,11 +120,16 @@ __device__ __forceinline__ void channel_rows(T* tile, T* conv_rows, uint32_t no,
     }
 }
 
-template <typename T, bool VEC, bool PACKED>
+template <bool HALF> struct decoded_of { typedef float type; typedef dh_f4 type4; };
+template <> struct decoded_of<true> { typedef _Float16 type; typedef dh_h4 type4; };
+
+template <typename T, bool VEC, bool PACKED, bool HALF = false>
 __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
 {
     constexpr uint32_t S = 64 * (4 / sizeof(T));
     typedef typename vec4_of<T>::type T4;
+    typedef typename decoded_of<HALF>::type O;
+    typedef typename decoded_of<HALF>::type4 O4;
     extern __shared__ __align__(16) unsigned char tile_bytes[];
     T* tile = reinterpret_cast<T*>(tile_bytes);
     const uint32_t b = blockIdx.y;
@@ -141,7 +147,7 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
     __syncthreads();
 
     T* __restrict__ maps = H.maps ? static_cast<T*>(H.maps) + plane_row * no : nullptr;
-    float* __restrict__ dec = P.out ? P.out + (size_t)b * P.per_image + L.first + ((size_t)a * hw + s0) * no : nullptr;
+    O* __restrict__ dec = P.out ? reinterpret_cast<O*>(P.out) + (size_t)b * P.per_image + L.first + ((size_t)a * hw + s0) * no : nullptr;
     const size_t plane_at = (size_t)b * P.rows_per_image + L.row_first + (size_t)a * hw + s0;
     const float stride = L.stride, aw = L.anchor_px[2 * a], ah = L.anchor_px[2 * a + 1];
     const uint32_t n = ns * no;
@@ -152,6 +158,10 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
             if (!dec) continue;
             const dh_f4 x = {(float)raw.x, (float)raw.y, (float)raw.z, (float)raw.w};
             float y[4] = {dh_sigmoid(x.x), dh_sigmoid(x.y), dh_sigmoid(x.z), dh_sigmoid(x.w)};
+            if (HALF) {                                                                        // yolo.py:58 on an fp16 tensor
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = dh_round_f16(y[k]);
+            }
             const uint32_t s = dh_div(e, P.no);
             const uint32_t c0 = e - s * no;
             if (c0 < 4 || c0 + 3 >= no) {           // the vector touches box channels of row s or of row s + 1 (never both)
@@ -165,9 +175,15 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
                 for (int k = 0; k < 4; ++k) {
                     const int c = k - k0;
                     const float sv = y[k];
-                    const float xy = (sv * 2.0f - 0.5f + ((c & 1) ? fgy : fgx)) * stride;     // yolo.py:60,66
                     const float t = sv * 2.0f;
-                    const float wh = (t * t) * ((c & 1) ? ah : aw);                           // yolo.py:61,67
+                    float xy, wh;
+                    if (HALF) {                       // the roundings of decode_box_half
+                        xy = dh_round_f16((dh_round_f16(t - 0.5f) + ((c & 1) ? fgy : fgx)) * stride);
+                        wh = dh_round_f16(dh_round_f16(t * t) * ((c & 1) ? ah : aw));
+                    } else {
+                        xy = (sv * 2.0f - 0.5f + ((c & 1) ? fgy : fgx)) * stride;             // yolo.py:60,66
+                        wh = (t * t) * ((c & 1) ? ah : aw);                                   // yolo.py:61,67
+                    }
                     if (c >= 0 && c < 4) y[k] = c < 2 ? xy : wh;
                 }
             }
@@ -180,8 +196,8 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
                     if (P.logit_plane) P.logit_plane[plane_at + s4] = k4 == 0 ? x.x : (k4 == 1 ? x.y : (k4 == 2 ? x.z : x.w));
                 }
             }
-            const dh_f4 o = {y[0], y[1], y[2], y[3]};
-            __builtin_nontemporal_store(o, reinterpret_cast<dh_f4*>(dec + e));
+            const O4 o = {(O)y[0], (O)y[1], (O)y[2], (O)y[3]};
+            __builtin_nontemporal_store(o, reinterpret_cast<O4*>(dec + e));
         }
     } else {
         for (uint32_t e = threadIdx.x; e < n; e += 256) {
@@ -190,14 +206,15 @@ __global__ void __launch_bounds__(256) k_yolo_head_maps(const head_params P)
             if (!dec) continue;
             const float x = (float)raw;
             float y = dh_sigmoid(x);
+            if (HALF) y = dh_round_f16(y);
             const uint32_t s = dh_div(e, P.no);
             const uint32_t c = e - s * no;
-            if (c < 4) y = decode_box(L, a * hw + s0 + s, c, y);
+            if (c < 4) y = HALF ? decode_box_half(L, a * hw + s0 + s, c, y) : decode_box(L, a * hw + s0 + s, c, y);
             if (c == 4 && P.obj_plane) {
                 P.obj_plane[plane_at + s] = y;
                 if (P.logit_plane) P.logit_plane[plane_at + s] = x;
             }
-            dec[e] = y;
+            dec[e] = (O)y;
         }
     }
 }
@@ -263,7 +280,7 @@ int head_setup(head_params& P, const void* const* conv_ptrs, void* const* map_pt
     return DH_OK;
 }
 
-template <typename T>
+template <typename T, bool HALF = false>
 int head_maps_run(const void* const* conv_ptrs, void* const* map_ptrs, const int* ny, const int* nx, int nl, int bs, int na,
                   int no, const float* anchor_px, const float* strides, float* out, float* obj_plane, float* obj_logit_plane,
                   void* stream)
@@ -284,13 +301,14 @@ int head_maps_run(const void* const* conv_ptrs, void* const* map_ptrs, const int
     P.out = out;
     P.obj_plane = obj_plane;
     P.logit_plane = obj_logit_plane;
-    vec = vec && (!out || dh_aligned16(out)) && no >= 7;
+    vec = vec && (!out || (HALF ? (reinterpret_cast<uintptr_t>(out) & 7u) == 0 : dh_aligned16(out))) && no >= 7;
+    if (HALF && out && (reinterpret_cast<uintptr_t>(out) & 1u)) return DH_ERR_ALIGN;
     const size_t lds = (size_t)64 * (4 / sizeof(T)) * no * sizeof(T);
     hipStream_t st = (hipStream_t)stream;
-    if (vec && packed) hipLaunchKernelGGL((k_yolo_head_maps<T, true, true>), dim3(gx, bs), dim3(256), lds, st, P);
-    else if (vec) hipLaunchKernelGGL((k_yolo_head_maps<T, true, false>), dim3(gx, bs), dim3(256), lds, st, P);
-    else if (packed) hipLaunchKernelGGL((k_yolo_head_maps<T, false, true>), dim3(gx, bs), dim3(256), lds, st, P);
-    else hipLaunchKernelGGL((k_yolo_head_maps<T, false, false>), dim3(gx, bs), dim3(256), lds, st, P);
+    if (vec && packed) hipLaunchKernelGGL((k_yolo_head_maps<T, true, true, HALF>), dim3(gx, bs), dim3(256), lds, st, P);
+    else if (vec) hipLaunchKernelGGL((k_yolo_head_maps<T, true, false, HALF>), dim3(gx, bs), dim3(256), lds, st, P);
+    else if (packed) hipLaunchKernelGGL((k_yolo_head_maps<T, false, true, HALF>), dim3(gx, bs), dim3(256), lds, st, P);
+    else hipLaunchKernelGGL((k_yolo_head_maps<T, false, false, HALF>), dim3(gx, bs), dim3(256), lds, st, P);
     return dh_launch_status();
 }
 
@@ -336,6 +354,15 @@ extern "C" int dh_yolo_head_maps_f16(const void* const* conv_ptrs, void* const* 
 {
     return head_maps_run<_Float16>(conv_ptrs, map_ptrs, ny, nx, nl, bs, na, no, anchor_px, strides, out, obj_plane,
                                    obj_logit_plane, stream);
+}
+
+extern "C" int dh_yolo_head_maps_half(const void* const* conv_ptrs, void* const* map_ptrs, const int* ny, const int* nx, int nl,
+                                      int bs, int na, int no, const float* anchor_px, const float* strides, void* out_f16,
+                                      float* obj_plane, void* stream)
+{
+    if (!out_f16) return DH_ERR_ARG;
+    return head_maps_run<_Float16, true>(conv_ptrs, map_ptrs, ny, nx, nl, bs, na, no, anchor_px, strides,
+                                         reinterpret_cast<float*>(out_f16), obj_plane, nullptr, stream);
 }
 
 extern "C" int dh_yolo_head_maps_bwd(const float* const* grad_map_ptrs, float* const* grad_conv_ptrs, const int* ny,

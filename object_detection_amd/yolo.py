@@ -247,25 +247,40 @@ def head_maps(convs, na):
     return list(_HeadMaps.apply(na, *convs))
 
 
-def head_maps_decode(convs, na, anchors, stride, lazy=False):
+def head_maps_decode(convs, na, anchors, stride, lazy=False, half_arithmetic=False):
     """Eval branch of Detect.forward after the convolutions (yolo.py:53-70): returns (decoded (bs, A, no), head maps).
     lazy: the maps are returned as permuted views of the convolution outputs instead of being written.
     One launch reads the convolution outputs once and writes both; the results equal head_maps + detect_decode bit for bit.
-    A half-precision head keeps fp16 maps; the decoded tensor is fp32, as detect_decode returns it for fp16 maps."""
+    A half-precision head keeps fp16 maps; the decoded tensor is fp32, as detect_decode returns it for fp16 maps -- or, with
+    half_arithmetic, the fp16 tensor of detect_decode(..., half_arithmetic=True) (a half-precision model's in-place decode)."""
     convs = [c.detach() for c in convs]
     bs, no, ny, nx = _head_geometry(convs, na)
+    if half_arithmetic and not all(c.is_cuda and c.dtype == torch.float16 for c in convs):
+        raise RuntimeError("head_maps_decode(half_arithmetic=True) needs fp16 convolution outputs")
     if not _head_kernel_takes(convs, no):
         maps = _torch_head_maps(convs, na, no)
-        return detect_decode(maps, anchors, stride), maps
+        return detect_decode(maps, anchors, stride, half_arithmetic=half_arithmetic), maps
     convs = [c.contiguous() for c in convs]
     nl = len(convs)
     dev = convs[0].device
     total = sum(na * h * w for h, w in zip(ny, nx))
-    anchor_px, strides = _anchor_pixels(anchors, stride)
+    anchor_px, strides = _anchor_pixels(anchors, stride, half_model=bool(half_arithmetic))
     if lazy:
         maps = [c.view(bs, na, no, h, w).permute(0, 1, 3, 4, 2) for c, h, w in zip(convs, ny, nx)]
     else:
         maps = [torch.empty((bs, na, h, w, no), dtype=convs[0].dtype, device=dev) for h, w in zip(ny, nx)]
+    if half_arithmetic:
+        out = torch.empty((bs, total, no), dtype=torch.float16, device=dev)
+        plane = torch.empty((bs, total), dtype=torch.float32, device=dev) if _USE_PLANES else None
+        with L.device_guard(dev):
+            made_on = L.raw_stream()
+            L.check(L.lib().dh_yolo_head_maps_half((L.c_void_p * nl)(*[c.data_ptr() for c in convs]),
+                                                   None if lazy else (L.c_void_p * nl)(*[m.data_ptr() for m in maps]),
+                                                   L.int_array(ny), L.int_array(nx), nl, bs, na, no, anchor_px, strides, L.ptr(out),
+                                                   L.ptr(plane), L.c_void_p(made_on)), "dh_yolo_head_maps_half")
+        if plane is not None:
+            _remember_planes(out, None, plane, None, made_on)
+        return out, maps
     out = torch.empty((bs, total, no), dtype=torch.float32, device=dev)
     planes = torch.empty((2, bs, total), dtype=torch.float32, device=dev)
     entry = L.lib().dh_yolo_head_maps_f16 if convs[0].dtype == torch.float16 else L.lib().dh_yolo_head_maps
@@ -369,8 +384,11 @@ class Detect(nn.Module):
             return x
         wants_grad = torch.is_grad_enabled() and any(c.requires_grad for c in x)
         if not self.training and not wants_grad and self.half_arithmetic and all(c.is_cuda and c.dtype == torch.float16 for c in x):
+            if self.inplace:          # layout change and the half model's decode in one launch
+                z, x[:] = head_maps_decode(x, self.na, self.anchors, self.stride, lazy=self.lazy_maps, half_arithmetic=True)
+                return z, x
             x[:] = head_maps(x, self.na)
-            return detect_decode(x, self.anchors, self.stride, half_arithmetic=True, inplace=self.inplace), x
+            return detect_decode(x, self.anchors, self.stride, half_arithmetic=True, inplace=False), x
         if self.training or wants_grad:
             x[:] = head_maps(x, self.na)
             return x if self.training else (detect_decode(x, self.anchors, self.stride), x)

@@ -266,3 +266,29 @@ def test_half_detect_module_detections_equal_forward_plus_nms(inplace):
         got = det.detections([f.clone() for f in feats], **kw)
         same_lists(got, want)
         assert sum(int(w.shape[0]) for w in want) > 0
+
+
+@pytest.mark.parametrize("nc,shapes", [(1, [(5, 5), (3, 3)]), (2, [(4, 6), (2, 3)]), (3, [(7, 5)]), (6, [(8, 8), (4, 4), (2, 2)]),
+                                       (7, [(9, 11), (4, 6), (2, 3)]), (11, [(8, 8), (4, 4)]), (80, [(20, 20), (10, 10), (5, 5)]),
+                                       (80, [(80, 80), (40, 40), (20, 20)]), (130, [(6, 10), (3, 5)])])
+def test_half_head_maps_decode_equals_the_two_launches(nc, shapes):
+    """Layout change and the half model's decode in one launch (what Detect.forward runs on an fp16 head): the maps of
+    head_maps and the fp16 tensor of detect_decode(half_arithmetic=True), bit for bit, on level sizes and row lengths that
+    take every form of the kernel; also with the maps left as views, and the objectness plane it leaves for NMS."""
+    from object_detection_amd.general import non_max_suppression
+    from object_detection_amd.yolo import detect_decode, head_maps, head_maps_decode, objectness_plane
+    rs = np.random.RandomState(100 + nc)
+    na, bs = 3, 2
+    anchors = torch.from_numpy(rs.uniform(1.0, 6.0, (len(shapes), na, 2)).astype(np.float32)).cuda()
+    strides = torch.tensor([8.0 * 2 ** i for i in range(len(shapes))])
+    convs = [torch.from_numpy(rs.normal(0, 1.5, (bs, na * (nc + 5), ny, nx)).astype(np.float32)).half().cuda() for ny, nx in shapes]
+    maps = head_maps(convs, na)
+    want = detect_decode(maps, anchors, strides, half_arithmetic=True)
+    for lazy in (False, True):
+        z, got_maps = head_maps_decode(convs, na, anchors, strides, lazy=lazy, half_arithmetic=True)
+        assert z.dtype == torch.float16 and torch.equal(z, want)
+        for a, b in zip(got_maps, maps):
+            assert a.dtype == torch.float16 and torch.equal(a, b)
+        plane = objectness_plane(z)
+        assert plane is not None and torch.equal(plane, z[:, :, 4].float())
+        same_lists(non_max_suppression(z, 0.05, 0.5), non_max_suppression(want.clone(), 0.05, 0.5))

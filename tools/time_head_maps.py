@@ -27,8 +27,10 @@ def torch_permute():
 
 
 def timed(fn, reps=30):
+    import gc
     for _ in range(5):
         fn()
+    gc.collect()                # a full collection inside the timed calls would add tens of milliseconds to them
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -78,6 +80,12 @@ rows += [
     ("fp16: detect_decode alone", lambda: yolo.detect_decode(h_maps, anchors, stride), elems * (2 + 4)),
     ("fp16: head_maps (layout change only)", lambda: yolo.head_maps(h_convs, na), elems * 4),
     ("fp16: head_maps_decode (fused)", lambda: yolo.head_maps_decode(h_convs, na, anchors, stride), elems * (2 + 2 + 4)),
+    ("fp16, half model's arithmetic: head_maps + detect_decode(half_arithmetic)",
+     lambda: yolo.detect_decode(yolo.head_maps(h_convs, na), anchors, stride, half_arithmetic=True), elems * (2 + 2 + 2 + 2)),
+    ("fp16, half model's arithmetic: head_maps_decode (fused)",
+     lambda: yolo.head_maps_decode(h_convs, na, anchors, stride, half_arithmetic=True), elems * (2 + 2 + 2)),
+    ("fp16, half model's arithmetic: head_maps_decode (fused, lazy maps)",
+     lambda: yolo.head_maps_decode(h_convs, na, anchors, stride, lazy=True, half_arithmetic=True), elems * (2 + 2)),
 ]
 # detections straight from the convolution outputs against Detect.forward + non_max_suppression
 from object_detection_amd import general as G  # noqa: E402
