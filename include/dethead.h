@@ -395,8 +395,9 @@ int dh_wh_iou(const float* wh1, const float* wh2, float* out, int64_t N, int64_t
  * out = heat where heat equals its kernel x kernel neighbourhood maximum, heat*0 elsewhere. */
 int dh_centernet_pool_nms(const float* heat, float* out, int64_t planes, int W, int H, int kernel, void* stream);
 
-/* decode_bbox (dataset.py:172-216): heat (B,C,W,H), size/offset (B,2,W,H) ->
- * det (B, W*H, 6) rows [x1,y1,x2,y2,conf,cls] (normalised, in cell order) and counts (B). */
+/* decode_bbox (dataset.py:172-216): heat (B,C,W,H), size/offset (B,2,W,H) -> counts (B) and det, room for B*W*H rows
+ * [x1,y1,x2,y2,conf,cls] (normalised): the rows of the whole batch packed, image after image, each image's in cell
+ * order -- image b owns counts[b] rows starting at row counts[0] + ... + counts[b-1]. */
 size_t dh_centernet_decode_workspace(int B, int W, int H);
 int dh_centernet_decode(const float* heat, const float* size, const float* offset, int B, int C, int W, int H,
                         double confidence, float* det, int* counts, void* workspace, size_t workspace_bytes,
@@ -405,8 +406,8 @@ int dh_centernet_decode(const float* heat, const float* size, const float* offse
 /* CenterNet postprocess, device part (object_detection/detectors/centernet/dataset.py:246-270): the detections of each
  * image regrouped by ascending class; with need_nms every class goes through torchvision nms(boxes, scores, nms_thres)
  * and keeps the survivors in score order (equal scores: input order), without it a class keeps its input order.
- * rows (*, 6) [x1,y1,x2,y2,conf,cls]: image b owns count[b] rows starting at row first[b] (so both a concatenation
- * and the padded (B, W*H, 6) buffer of dh_centernet_decode fit); max_rows >= every count, nc > every class id.
+ * rows (*, 6) [x1,y1,x2,y2,conf,cls]: image b owns count[b] rows starting at row first[b] (a concatenation, the
+ * packed buffer of dh_centernet_decode, or a padded one); max_rows >= every count, nc > every class id.
  * out: image b's result starts at row out_first[b] and has out_count[b] <= count[b] rows.  first, count, out_first,
  * out_count are device arrays of n_img ints.  One sequence of launches for the whole batch; nothing returns to the host. */
 size_t dh_group_nms_workspace(int n_img, int max_rows, int nc);

@@ -24,10 +24,10 @@ def pool_nms(heat, kernel=3):
 
 
 class _Decoded(list):
-    """decode_bbox's per-image list, which also remembers the padded device buffer the entries are views of, so that
+    """decode_bbox's per-image list, which also remembers the packed device buffer the entries are views of, so that
     postprocess can hand the whole batch to one kernel sequence without concatenating them again."""
-    buffer = None        # (B, W*H, 6)
-    counts = None        # device int32 (B,)
+    buffer = None        # (rows of the whole batch, 6), image after image
+    first = None         # first row of every image in it
     num_classes = 0
     version = -1         # autograd version counter of the buffer when it was written
 
@@ -35,8 +35,9 @@ class _Decoded(list):
 def decode_bbox(pred_cls, pred_size, pred_offset, confidence, device=None):
     """Per image: [] or (k,6) [x1,y1,x2,y2,conf,cls] normalised boxes in cell order (dataset.py:172-216).
 
-    Peak filter, tanh, best class and thresholding run in two launches for the whole batch; one
-    host copy of the per-image counts replaces the reference's per-image loop.
+    Peak filter, tanh, best class and thresholding run in three launches for the whole batch, which leave the rows of all
+    images packed in one buffer; one host copy of the per-image counts and one split of that buffer replace the
+    reference's per-image loop.
     """
     heat = L.dev_f32(pred_cls, "pred_cls").contiguous()
     size = L.dev_f32(pred_size, "pred_size").contiguous()
@@ -47,13 +48,18 @@ def decode_bbox(pred_cls, pred_size, pred_offset, confidence, device=None):
     lib = L.lib()
     ws_bytes = lib.dh_centernet_decode_workspace(B, W, H)
     ws = L.workspace(ws_bytes, heat.device)
-    det = torch.empty((B, W * H, 6), dtype=torch.float32, device=heat.device)
+    det = torch.empty((B * W * H, 6), dtype=torch.float32, device=heat.device)
     counts = torch.empty(B, dtype=torch.int32, device=heat.device)
     with L.device_guard(heat.device):
         L.check(lib.dh_centernet_decode(L.ptr(heat), L.ptr(size), L.ptr(off), B, C, W, H, float(confidence), L.ptr(det),
                                         L.ptr(counts), L.ptr(ws), ws_bytes, L.stream()), "dh_centernet_decode")
-    out = _Decoded(d.narrow(0, 0, k) if k else [] for d, k in zip(det.unbind(0), counts.tolist()))
-    out.buffer, out.counts, out.num_classes, out.version = det, counts, int(C), det._version
+    sizes = counts.tolist()
+    total = sum(sizes)
+    out = _Decoded(d if k else [] for d, k in zip(det[:total].split(sizes), sizes)) if B else _Decoded()
+    first = [0] * B
+    for i in range(1, B):
+        first[i] = first[i - 1] + sizes[i - 1]
+    out.buffer, out.first, out.num_classes, out.version = det, first, int(C), det._version
     return out
 
 
@@ -79,12 +85,11 @@ def _group_by_class(prediction, need_nms, nms_thres):
     for i in range(1, B):
         out_first[i] = out_first[i - 1] + sizes[i - 1]
     total = out_first[-1] + sizes[-1]
-    if isinstance(prediction, _Decoded) and prediction.buffer is not None and all(
-            len(d) == 0 or (d.data_ptr() == prediction.buffer[i].data_ptr() and d._version == prediction.version)
+    if isinstance(prediction, _Decoded) and prediction.buffer is not None and len(prediction.first) == B and all(
+            len(d) == 0 or (d.data_ptr() == prediction.buffer.data_ptr() + 24 * prediction.first[i] and d._version == prediction.version)
             for i, d in enumerate(prediction)):      # still the untouched views decode_bbox made
-        rows = prediction.buffer.view(-1, 6)
-        stride = prediction.buffer.shape[1]
-        first = [i * stride for i in range(B)]
+        rows = prediction.buffer
+        first = prediction.first
         nc = prediction.num_classes
     else:
         rows = torch.cat([L.dev_f32(d, f"prediction[{i}]").reshape(-1, 6) for i, d in enumerate(prediction) if len(d)])

@@ -274,7 +274,8 @@ __global__ void __launch_bounds__(256) k_cn_best_class3v(const float* __restrict
 }
 
 // order-preserving compaction of the cells above the confidence threshold: workgroups of CN_CHUNK cells count their
-// hits, then every workgroup adds up the counts of the chunks before it and writes its own rows
+// hits, then every workgroup adds up the counts of the chunks before it -- of its own image and of all images before it,
+// so that the rows of the whole batch end up packed, image after image -- and writes its own rows
 #define CN_CHUNK 1024
 
 __global__ void __launch_bounds__(CN_CHUNK) k_cn_count(const float* __restrict__ conf, int cells, float confidence,
@@ -299,15 +300,23 @@ __global__ void __launch_bounds__(CN_CHUNK) k_cn_emit(const float* __restrict__ 
                                                       int W, int H, float confidence, const int* __restrict__ chunk_counts,
                                                       float* __restrict__ det, int* __restrict__ counts)
 {
-    __shared__ int s_w[CN_CHUNK / 64], s_prev[CN_CHUNK / 64];
+    __shared__ int s_w[CN_CHUNK / 64], s_prev[CN_CHUNK / 64], s_prev_img[CN_CHUNK / 64];
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int cells = W * H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cell = chunk * CN_CHUNK + threadIdx.x;
-    int prev = 0;                                                                     // hits in the chunks before this one
-    for (int k = threadIdx.x; k < chunk; k += CN_CHUNK) prev += chunk_counts[(size_t)b * gridDim.x + k];
+    int prev = 0, prev_img = 0;                      // hits in the chunks before this one: of the batch / of this image
+    const int own_first = b * (int)gridDim.x;
+    for (int k = threadIdx.x; k < own_first + chunk; k += CN_CHUNK) {
+        const int c = chunk_counts[k];
+        prev += c;
+        prev_img += k >= own_first ? c : 0;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) prev += __shfl_xor(prev, o, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+        prev += __shfl_xor(prev, o, 64);
+        prev_img += __shfl_xor(prev_img, o, 64);
+    }
     float cf = 0.0f;
     bool take = false;
     if (cell < cells) {
@@ -315,14 +324,14 @@ __global__ void __launch_bounds__(CN_CHUNK) k_cn_emit(const float* __restrict__ 
         take = cf > confidence;                                                       // dataset.py:189
     }
     const unsigned long long bm = __ballot(take);
-    if (lane == 0) { s_w[wave] = __popcll(bm); s_prev[wave] = prev; }
+    if (lane == 0) { s_w[wave] = __popcll(bm); s_prev[wave] = prev; s_prev_img[wave] = prev_img; }
     __syncthreads();
-    int before = 0, all = 0;
+    int before = 0, all = 0;                          // rows of the batch before this wave's; hits of this image so far
 #pragma unroll
     for (int w = 0; w < CN_CHUNK / 64; ++w) {
         const int c = s_w[w];
         if (w < wave) before += c;
-        all += c + s_prev[w];
+        all += c + s_prev_img[w];
         before += s_prev[w];
     }
     if (take) {
@@ -333,7 +342,7 @@ __global__ void __launch_bounds__(CN_CHUNK) k_cn_emit(const float* __restrict__ 
         const float cx = (float)x + of[cell], cy = (float)y + of[cells + cell];        // dataset.py:197-198
         const float hw = sz[cell] / 2, hh = sz[cells + cell] / 2;
         const float fw = (float)W, fh = (float)H;
-        float* __restrict__ d = det + ((size_t)b * cells + pos) * 6;
+        float* __restrict__ d = det + (size_t)pos * 6;
         d[0] = __fdiv_rn(cx - hw, fw);                                                // dataset.py:200-205
         d[1] = __fdiv_rn(cy - hh, fh);
         d[2] = __fdiv_rn(cx + hw, fw);
