@@ -321,19 +321,10 @@ def detect_nms(levels, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes
         from .yolo import detect_decode
         return non_max_suppression(detect_decode(levels, anchors, stride, half_arithmetic=half_arithmetic), conf_thres, iou_thres,
                                    classes, agnostic, multi_label, labels, max_det, merge)
-    cap, k_select = None, None
-    while True:
-        rows, meta, cap = detect_nms_launch(levels, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
-                                            max_det, cap, k_select, merge, half_arithmetic=half_arithmetic)
-        if rows is None:
-            return [torch.zeros((0, 6), device=levels[0].device)] * levels[0].shape[0]
-        result, need = nms_finish(rows, meta, cap)
-        if result is not None:
-            return result
-        if need < 0:
-            k_select = _next_attempt(rows, need)
-        else:
-            cap = need
+    return _until_complete(lambda cap, k_select: detect_nms_launch(levels, anchors, stride, conf_thres, iou_thres, classes, agnostic,
+                                                                   multi_label, max_det, cap, k_select, merge,
+                                                                   half_arithmetic=half_arithmetic),
+                           levels[0].device, levels[0].shape[0])
 
 
 def conv_nms(convs, na, anchors, stride, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
@@ -352,19 +343,10 @@ def conv_nms(convs, na, anchors, stride, conf_thres=0.25, iou_thres=0.45, classe
         else:
             z = head_maps_decode(convs, na, anchors, stride, lazy=True)[0]
         return non_max_suppression(z, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det, merge)
-    cap, k_select = None, None
-    while True:
-        rows, meta, cap = detect_nms_launch(convs, anchors, stride, conf_thres, iou_thres, classes, agnostic, multi_label,
-                                            max_det, cap, k_select, merge, conv_na=na, half_arithmetic=half_arithmetic)
-        if rows is None:
-            return [torch.zeros((0, 6), device=convs[0].device)] * convs[0].shape[0]
-        result, need = nms_finish(rows, meta, cap)
-        if result is not None:
-            return result
-        if need < 0:
-            k_select = _next_attempt(rows, need)
-        else:
-            cap = need
+    return _until_complete(lambda cap, k_select: detect_nms_launch(convs, anchors, stride, conf_thres, iou_thres, classes, agnostic,
+                                                                   multi_label, max_det, cap, k_select, merge, conv_na=na,
+                                                                   half_arithmetic=half_arithmetic),
+                           convs[0].device, convs[0].shape[0])
 
 
 def nms_meta_to_host(meta, pinned=None):
@@ -433,12 +415,20 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     of the per-image counts; the returned tensors are views of one packed buffer.
     The reference's 10 s wall-clock bail-out (general.py:734-736) is not reproduced.
     """
+    return _until_complete(lambda cap, k_select: nms_launch(prediction, conf_thres, iou_thres, classes, agnostic, multi_label,
+                                                            labels, max_det, cap, k_select, merge),
+                           prediction.device, prediction.shape[0])
+
+
+def _until_complete(launch, device, bs):
+    """Runs launch(cap, k_select) -> (rows, meta, cap) and reads its bookkeeping back until it covers every image: an
+    attempt that left some image to a more general one is followed by that one, a candidate list that overflowed by a
+    launch with room for all of it.  Returns the per-image views."""
     cap, k_select = None, None
     while True:
-        rows, meta, cap = nms_launch(prediction, conf_thres, iou_thres, classes, agnostic, multi_label, labels, max_det, cap,
-                                     k_select, merge)
+        rows, meta, cap = launch(cap, k_select)
         if rows is None:
-            return [torch.zeros((0, 6), device=prediction.device)] * prediction.shape[0]
+            return [torch.zeros((0, 6), device=device)] * bs
         result, need = nms_finish(rows, meta, cap)
         if result is not None:
             return result

@@ -41,6 +41,27 @@ __global__ void __launch_bounds__(256) k_copy_stride(const f4* __restrict__ in, 
     }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by their index; here XCD x streams the x-th contiguous eighth of the
+// buffer (CONTIG) instead of every eighth tile of it.
+template <int U, int NT>
+__global__ void __launch_bounds__(256) k_copy_xcd(const f4* __restrict__ in, f4* __restrict__ out, size_t n)
+{
+    const unsigned per = (gridDim.x + 7) / 8;
+    const unsigned blk = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    const size_t base = (size_t)blk * (256 * U) + threadIdx.x;
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n) v[u] = (NT & 1) ? __builtin_nontemporal_load(in + i) : in[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * 256;
+        if (i < n) { if (NT & 2) __builtin_nontemporal_store(v[u], out + i); else out[i] = v[u]; }
+    }
+}
+
 template <int U>
 __global__ void __launch_bounds__(256) k_write(f4* __restrict__ out, size_t n)
 {
@@ -75,6 +96,8 @@ int main()
 #define G(U) dim3((unsigned)((n + 256 * U - 1) / (256 * U)))
 #define COPY(U, NT) timeit("copy unroll " #U " nt " #NT, 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy<U, NT>), G(U), dim3(256), 0, 0, in, out, n); })
     COPY(1, 0); COPY(1, 3); COPY(2, 3); COPY(4, 0); COPY(4, 1); COPY(4, 2); COPY(4, 3); COPY(8, 0); COPY(8, 3); COPY(16, 3);
+#define XCD(U, NT) timeit("copy, an eighth of the buffer per XCD, unroll " #U " nt " #NT, 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy_xcd<U, NT>), dim3((G(U).x + 7) / 8 * 8), dim3(256), 0, 0, in, out, n); })
+    XCD(1, 3); XCD(2, 3); XCD(4, 3); XCD(2, 0);
 #define STRIDE(U, NT, GRID) timeit("grid-stride " #GRID " blocks unroll " #U " nt " #NT, 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy_stride<U, NT>), dim3(GRID), dim3(256), 0, 0, in, out, n); })
     STRIDE(4, 3, 2048); STRIDE(4, 3, 4096); STRIDE(8, 3, 2048); STRIDE(4, 0, 2048); STRIDE(1, 3, 4096); STRIDE(1, 3, 8192);
     timeit("hipMemcpyAsync D2D", 2.0 * bytes, [&] { hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, 0); });
