@@ -208,7 +208,9 @@ __global__ void __launch_bounds__(256) k_yolo_decode_lanes(const decode_params P
     float* __restrict__ fy = s_y + wave * (U * 256);
     const float* __restrict__ fx = s_x + wave * (U * 256);
     for (uint32_t s = lane; s < specials; s += 64) {
-        const uint32_t u = s / per_span;
+        uint32_t u = 0;                                        // s / per_span without a division (U <= 4)
+#pragma unroll
+        for (int q = 1; q < U; ++q) u += s >= (uint32_t)q * per_span ? 1u : 0u;
         const uint32_t t = s - u * per_span;
         const uint32_t ri = t / 5u, c = t - ri * 5u;
         const uint32_t e0 = (vw + u * 256) * 4;                // first element of the span

@@ -62,6 +62,26 @@ __global__ void __launch_bounds__(256) k_copy_xcd(const f4* __restrict__ in, f4*
     }
 }
 
+// Launch shapes around the best one: workgroups of TPB threads, U vectors per lane, either a workgroup's U tiles one after
+// the other (ADJ = 0: lane i holds vectors i, i + TPB, ...) or a lane's U vectors next to each other (ADJ = 1: 16*U bytes
+// per lane).
+template <int TPB, int U, int ADJ>
+__global__ void __launch_bounds__(TPB) k_copy_shape(const f4* __restrict__ in, f4* __restrict__ out, size_t n)
+{
+    const size_t base = (size_t)blockIdx.x * (TPB * U) + (ADJ ? threadIdx.x * U : threadIdx.x);
+    f4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * (ADJ ? 1 : TPB);
+        if (i < n) v[u] = __builtin_nontemporal_load(in + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t i = base + (size_t)u * (ADJ ? 1 : TPB);
+        if (i < n) __builtin_nontemporal_store(v[u], out + i);
+    }
+}
+
 template <int U>
 __global__ void __launch_bounds__(256) k_write(f4* __restrict__ out, size_t n)
 {
@@ -98,6 +118,9 @@ int main()
     COPY(1, 0); COPY(1, 3); COPY(2, 3); COPY(4, 0); COPY(4, 1); COPY(4, 2); COPY(4, 3); COPY(8, 0); COPY(8, 3); COPY(16, 3);
 #define XCD(U, NT) timeit("copy, an eighth of the buffer per XCD, unroll " #U " nt " #NT, 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy_xcd<U, NT>), dim3((G(U).x + 7) / 8 * 8), dim3(256), 0, 0, in, out, n); })
     XCD(1, 3); XCD(2, 3); XCD(4, 3); XCD(2, 0);
+#define SHAPE(TPB, U, ADJ) timeit("copy nt 3, " #TPB " threads, unroll " #U ", adjacent " #ADJ, 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy_shape<TPB, U, ADJ>), dim3((unsigned)((n + TPB * U - 1) / (TPB * U))), dim3(TPB), 0, 0, in, out, n); })
+    SHAPE(64, 1, 0); SHAPE(64, 2, 0); SHAPE(64, 2, 1); SHAPE(64, 4, 0); SHAPE(128, 1, 0); SHAPE(128, 2, 0); SHAPE(128, 2, 1);
+    SHAPE(256, 2, 1); SHAPE(512, 1, 0); SHAPE(512, 2, 0); SHAPE(1024, 1, 0);
 #define STRIDE(U, NT, GRID) timeit("grid-stride " #GRID " blocks unroll " #U " nt " #NT, 2.0 * bytes, [&] { hipLaunchKernelGGL((k_copy_stride<U, NT>), dim3(GRID), dim3(256), 0, 0, in, out, n); })
     STRIDE(4, 3, 2048); STRIDE(4, 3, 4096); STRIDE(8, 3, 2048); STRIDE(4, 0, 2048); STRIDE(1, 3, 4096); STRIDE(1, 3, 8192);
     timeit("hipMemcpyAsync D2D", 2.0 * bytes, [&] { hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, 0); });
