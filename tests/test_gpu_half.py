@@ -241,6 +241,11 @@ def test_fused_half_conv_nms_equals_the_two_calls(kw):
     got = conv_nms(convs, 3, anchors, strides, half_arithmetic=True, **kw)
     same_lists(got, want)
     assert sum(w.shape[0] for w in want) > 5
+    # apriori labels join the rows of the decoded tensor: the call makes it and runs the two calls itself
+    labels = [torch.from_numpy(np.concatenate([rs.randint(0, 80, (n, 1)), rs.uniform(20, 600, (n, 4))], 1).astype(np.float32))
+              for n in (2, 0, 1, 3)]
+    want = non_max_suppression(detect_decode(maps, anchors, strides, half_arithmetic=True), labels=labels, **kw)
+    same_lists(conv_nms(convs, 3, anchors, strides, half_arithmetic=True, labels=labels, **kw), want)
 
 
 @pytest.mark.parametrize("inplace", [True, False])
