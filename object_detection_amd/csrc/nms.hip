@@ -33,6 +33,11 @@
 //       (k_nms_groups, k_nms_groups_final);
 //       otherwise the best k_select keys are selected and sorted in LDS (k_select_sort) ahead of stages 3-6.
 // Each of them is exact for the rows it returns or flags the image (needs_full) for the next, more general attempt.
+//
+// Sources of the rows (nms_source): the decoded fp32 tensor; the raw head maps or the outputs of the head's convolutions,
+// fp32 or fp16, decoded on the fly for the rows that need it; and, behind a half-precision model (val.py:129-130), the fp16
+// decoded tensor itself or the fp16 maps with that model's roundings (half_arith) -- the kernels are instantiated per
+// element type, and per arithmetic where the candidate search forms obj * cls.
 #include <mutex>
 
 #include "dh_common.h"
