@@ -11,6 +11,6 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 --pre-roll 0 --post-roll 0 > $O/write.log 2>&1
 cd $R
 timeout -k 10 300 python3 bench.py > $O/bench_line.json 2> $O/bench.err
-timeout -k 10 200 python3 tools/time_configs.py val,dense,sweep > $O/time_configs.txt 2>&1
+timeout -k 10 200 python3 tools/time_configs.py val,dense,sweep --iters 20 > $O/time_configs.txt 2>&1
 tail -1 $O/bench_line.json
 cat $O/time_configs.txt
