@@ -16,8 +16,11 @@ import bench  # noqa: E402
 
 
 def timed(fn, iters, warm=5):
+    import gc
     for _ in range(warm):
         fn()
+    gc.collect()          # a full collection inside the timed calls would add tens of milliseconds to them
+    gc.disable()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -25,6 +28,7 @@ def timed(fn, iters, warm=5):
         fn()
     b.record()
     torch.cuda.synchronize()
+    gc.enable()
     return a.elapsed_time(b) / iters * 1e3   # us
 
 
