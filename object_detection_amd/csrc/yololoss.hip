@@ -79,12 +79,19 @@ __device__ __forceinline__ float bce_grad(float x, float t, float pw, float gamm
     const float s = 1.0f / (1.0f + expf(-x));
     const float d = lw * s - pw * t;          // = (1-t) - lw*(1-s) without the cancellation at small s
     if (!(gamma > 0.0f)) return d;
-    const float l = (1.0f - t) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.0f));
-    const float pt = t * s + (1.0f - t) * (1.0f - s);
+    // FocalLoss (loss.py:45-62) differentiated.  Evaluated in the order of the forward formula, the loss value
+    // x + (softplus(-|x|) - x) and the modulating base 1 - (1 - s) lose 1e-4 of their value to rounding at the usual
+    // negative logits (the fp32 reference carries that noise too).  Both are formed here from terms of one sign:
+    //   l      = lw*softplus(-|x|) + (x < 0 ? |x|*pw*t : (1-t)*x)
+    //   1 - pt = t*(1-s) + (1-t)*s,   1 - s = sigmoid(-x)
+    const float e = expf(-fabsf(x));
+    const float sp = log1pf(e);
+    const float l = x < 0.0f ? lw * sp + (-x) * (pw * t) : (1.0f - t) * x + lw * sp;
+    const float sn = x < 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
     const float af = t * FOCAL_ALPHA + (1.0f - t) * (1.0f - FOCAL_ALPHA);
-    const float om = 1.0f - pt;
+    const float om = t * sn + (1.0f - t) * s;
     const float mf = powf(om, gamma);
-    const float dmf = -gamma * powf(om, gamma - 1.0f) * ((2.0f * t - 1.0f) * s * (1.0f - s));
+    const float dmf = -gamma * powf(om, gamma - 1.0f) * ((2.0f * t - 1.0f) * s * sn);
     return af * (d * mf + l * dmf);
 }
 

@@ -143,7 +143,7 @@ class YoloLossOracle:
         self.sort_obj_iou = False
 
     def _bce(self, logits, target, pos_weight):
-        pw = torch.tensor([pos_weight])
+        pw = torch.tensor([pos_weight], dtype=logits.dtype)
         g = self.hyp["fl_gamma"]
         if g > 0:
             return _focal(F.binary_cross_entropy_with_logits(logits, target, pos_weight=pw, reduction="none"),
@@ -155,7 +155,10 @@ class YoloLossOracle:
         return build_targets(shapes, targets.detach().cpu().numpy(), self.anchors.numpy(), self.hyp["anchor_t"])
 
     def __call__(self, p, targets):
-        lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+        """p in float32 is the reference's arithmetic; p in float64 evaluates the same formulas (same fp32 assignment)
+        in double precision, the yardstick for gradient entries that are differences of nearly equal terms."""
+        dt = p[0].dtype
+        lcls, lbox, lobj = torch.zeros(1, dtype=dt), torch.zeros(1, dtype=dt), torch.zeros(1, dtype=dt)
         assigned = self.targets_for(p, targets)
         for lvl, pi in enumerate(p):
             t = assigned[lvl]
@@ -165,9 +168,9 @@ class YoloLossOracle:
             if n:
                 ps = pi[b, a, gj, gi]                                                  # loss.py:129
                 pxy = ps[:, :2].sigmoid() * 2 - 0.5
-                pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * torch.from_numpy(t["anch"])
+                pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * torch.from_numpy(t["anch"]).to(dt)
                 pbox = torch.cat((pxy, pwh), 1)
-                iou = bbox_iou_yolo(pbox.T, torch.from_numpy(t["tbox"]), x1y1x2y2=False, CIoU=True)
+                iou = bbox_iou_yolo(pbox.T, torch.from_numpy(t["tbox"]).to(dt), x1y1x2y2=False, CIoU=True)
                 lbox = lbox + (1.0 - iou).mean()                                       # loss.py:136
                 score_iou = iou.detach().clamp(0).type(tobj.dtype)
                 if self.sort_obj_iou:                                                  # loss.py:140-142

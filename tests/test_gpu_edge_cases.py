@@ -8,7 +8,7 @@ from oracle import nms as onms
 from oracle import yolo as oy
 from tests._synth import synth_head, synth_pred, synth_targets
 from tests.test_gpu_nms import same_lists
-from tests._checks import decoded_close, level_rows
+from tests._checks import all_grads_close, decoded_close, level_rows, loss_grads64
 from tests.test_gpu_yolo_loss import FakeModel, close
 
 pytestmark = pytest.mark.gpu
@@ -163,8 +163,7 @@ def test_loss_and_decode_with_more_levels(strides):
     gg = torch.autograd.grad(gl, d)
     close(gl, wl.detach())
     close(gi, wi)
-    for a, b in zip(gg, wg):
-        close(a, b)
+    all_grads_close(gg, wg, loss_grads64(want_fn, levels, targets))
     z = detect_decode([x.detach() for x in d], anchors.cuda(), torch.tensor(strides))
     want = oy.detect_decode([T(x) for x in levels], anchors, list(strides))
     decoded_close(z, want, level_rows(levels), strides)

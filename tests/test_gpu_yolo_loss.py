@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import yolo as oy
-from tests._checks import decoded_close, level_rows
+from tests._checks import all_grads_close, decoded_close, level_rows, loss_grads64
 from tests._synth import synth_head, synth_targets
 from tests.test_oracle_golden import HYP_KEYS
 
@@ -35,6 +35,7 @@ def make_loss(anchors, nc, hyp, autobalance=False):
 
 
 def close(got, want, rtol=1e-5, floor=1e-6):
+    """Loss values and loss items (a handful of numbers of one magnitude); gradients go through all_grads_close."""
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
     scale = float(np.abs(want).max()) if want.size else 0.0
@@ -92,19 +93,32 @@ def golden_loss(g, tag):
     return crit, autobal, calls
 
 
+def golden_oracle(g, tag):
+    """The oracle with the same settings: its float64 evaluation is the yardstick for ill-conditioned gradient entries."""
+    img, bs, nc, autobal, calls = (int(v) for v in g[f"{tag}_meta"])
+    hyp = dict(zip(HYP_KEYS, (float(v) for v in g[f"{tag}_hyp"])))
+    o = oy.YoloLossOracle(T(g["anchors"]), hyp, nc=nc, autobalance=bool(autobal))
+    if f"{tag}_opts" in g:
+        o.sort_obj_iou, o.gr = bool(g[f"{tag}_opts"][0]), float(g[f"{tag}_opts"][1])
+    return o
+
+
 @pytest.mark.parametrize("tag", LOSS_TAGS)
 def test_compute_loss_golden(golden, tag):
     g = golden("compute_loss")
     crit, autobal, calls = golden_loss(g, tag)
+    oracle = golden_oracle(g, tag)
+    levels, tg = [g[f"{tag}_p{l}"] for l in range(3)], g[f"{tag}_targets"].reshape(-1, 6)
     for c in range(calls):
-        p = [T(g[f"{tag}_p{l}"]).cuda().requires_grad_(True) for l in range(3)]
-        loss, items = crit(p, T(g[f"{tag}_targets"]).reshape(-1, 6).cuda())
+        p = [T(x).cuda().requires_grad_(True) for x in levels]
+        loss, items = crit(p, T(tg).cuda())
         assert loss.shape == (1,) and items.shape == (3,) and not items.requires_grad
         grads = torch.autograd.grad(loss, p)
         close(loss, g[f"{tag}_call{c}_loss"])
         close(items, g[f"{tag}_call{c}_items"])
-        for l in range(3):
-            close(grads[l], g[f"{tag}_call{c}_grad{l}"])
+        all_grads_close(grads, [g[f"{tag}_call{c}_grad{l}"] for l in range(3)], loss_grads64(oracle, levels, tg))
+        if autobal:
+            oracle([T(x) for x in levels], T(tg))        # the oracle's balance weights move with the calls
     if autobal:
         close(np.array(crit.balance), g[f"{tag}_balance"])
 
@@ -127,8 +141,7 @@ def test_compute_loss_bs8_640_vs_oracle():
     gg = torch.autograd.grad(gl * 3.0, d)
     close(gl, wl.detach())
     close(gi, wi)
-    for a, b in zip(gg, wg):
-        close(a, b)
+    all_grads_close(gg, wg, loss_grads64(want_fn, levels, targets, 3.0))
     # property: the objectness gradient is dense, every other channel is zero off the assigned cells
     nz = (gg[0][..., :4] != 0).any(-1).sum().item()
     assert 0 < nz <= 5 * 3 * 80
@@ -162,14 +175,14 @@ def test_full_size_bs64_640_pipeline_vs_oracle():
     gg = torch.autograd.grad(gl, d)
     close(gl, wl.detach())
     close(gi, wi)
-    for a, b in zip(gg, wg):
-        close(a, b)
+    w64 = loss_grads64(want_fn, levels, targets)()
+    all_grads_close(gg, wg, w64)
     # the fused forward+backward entry (five launches) against the same oracle values
     fl, fi, fg = crit.forward_backward(d, T(targets).cuda())
     close(fl, wl.detach())
     close(fi, wi)
-    for a, b in zip(fg, wg):
-        close(a, b)
+    all_grads_close(fg, wg, w64)
+    del w64
     assert int(crit.last_stats[3].item()) == sum(int(c) for c in crit.last_positive_counts.tolist()) > 3000
     del gg, wg, fg
     wz = oy.detect_decode([T(x) for x in levels], anchors, oy.YOLOV5S_STRIDES)
@@ -244,7 +257,7 @@ def test_forward_backward_in_two_halves_matches_the_fused_call():
         close(l1, l0, rtol=1e-6)
         close(i1, i0, rtol=1e-6)
         for a, b in zip(g1, g0):
-            close(a, b, rtol=1e-6)
+            assert torch.equal(a, b)          # the same kernels on the same values
     with pytest.raises(RuntimeError):
         crit.forward_backward([x.clone() for x in levels], targets, positives=st)
 
@@ -278,8 +291,7 @@ def test_gradient_is_bit_reproducible_on_shared_cells():
     wl, wi = oy.YoloLossOracle(anchors, hyp, nc=80)(p, T(crowd))
     wg = torch.autograd.grad(wl, p)
     close(l0, wl.detach())
-    for a, b in zip(g0, wg):
-        close(a, b)
+    all_grads_close(g0, wg, loss_grads64(oy.YoloLossOracle(anchors, hyp, nc=80), levels, crowd), suspects=0.05)
     # the autograd path runs the same kernels
     q = [x.clone().requires_grad_(True) for x in d]
     la, _ = crit(q, tg)
@@ -291,8 +303,8 @@ def test_gradient_is_bit_reproducible_on_shared_cells():
     wl, wi = oy.YoloLossOracle(anchors, hyp, nc=80)(p, T(many))
     wg = torch.autograd.grad(wl, p)
     close(lm, wl.detach())
-    for a, b in zip(gm, wg):
-        close(a, b, rtol=2e-5)
+    # 120 terms per element, added by atomics in any order: 2e-5
+    all_grads_close(gm, wg, loss_grads64(oy.YoloLossOracle(anchors, hyp, nc=80), levels, many), rtol=2e-5, suspects=1.0)
 
 
 def test_forward_backward_autobalance_golden(golden):
@@ -304,13 +316,15 @@ def test_forward_backward_autobalance_golden(golden):
     assert autobal and calls > 1
     hyp = dict(zip(HYP_KEYS, (float(v) for v in g[f"{tag}_hyp"])))
     crit = make_loss(T(g["anchors"]), nc, hyp, True)
+    oracle = golden_oracle(g, tag)
     for c in range(calls):
         p = [T(g[f"{tag}_p{l}"]).cuda() for l in range(3)]
         loss, items, grads = crit.forward_backward(p, T(g[f"{tag}_targets"]).reshape(-1, 6).cuda())
         close(loss, g[f"{tag}_call{c}_loss"])
         close(items, g[f"{tag}_call{c}_items"])
-        for l in range(3):
-            close(grads[l], g[f"{tag}_call{c}_grad{l}"])
+        levels, tg = [g[f"{tag}_p{l}"] for l in range(3)], g[f"{tag}_targets"].reshape(-1, 6)
+        all_grads_close(grads, [g[f"{tag}_call{c}_grad{l}"] for l in range(3)], loss_grads64(oracle, levels, tg))
+        oracle([T(x) for x in levels], T(tg))
     close(np.array(crit.balance), g[f"{tag}_balance"])
 
 
@@ -327,8 +341,8 @@ def test_forward_backward_sort_obj_iou_golden(golden, tag):
         loss, items, grads = crit.forward_backward(p, tg, **kw)
         close(loss, g[f"{tag}_call0_loss"])
         close(items, g[f"{tag}_call0_items"])
-        for l in range(3):
-            close(grads[l], g[f"{tag}_call0_grad{l}"])
+        all_grads_close(grads, [g[f"{tag}_call0_grad{l}"] for l in range(3)],
+                        loss_grads64(golden_oracle(g, tag), [g[f"{tag}_p{l}"] for l in range(3)], g[f"{tag}_targets"].reshape(-1, 6)))
 
 
 def test_sort_obj_iou_on_crowded_cells_vs_oracle():
@@ -357,17 +371,17 @@ def test_sort_obj_iou_on_crowded_cells_vs_oracle():
         wl, wi = want_fn(p, T(targets))
         wg = torch.autograd.grad(wl, p)
         assert abs(float(plain(p, T(targets))[1][1]) - float(wi[1])) > 1e-4 * float(wi[1])    # the flag matters here
+        w64 = loss_grads64(want_fn, levels, targets)()
+        tol = dict(rtol=2e-5, suspects=1.0) if targets is many else dict(suspects=0.05)     # 120 atomically added terms: 2e-5
         loss, items, grads = crit.forward_backward(d, T(targets).cuda())
         close(loss, wl.detach())
         close(items, wi)
-        for a, b in zip(grads, wg):
-            close(a, b, rtol=2e-5)
+        all_grads_close(grads, wg, w64, **tol)
         q = [x.clone().requires_grad_(True) for x in d]
         la, ia = crit(q, T(targets).cuda())
         close(la, wl.detach())
         close(ia, wi)
-        for a, b in zip(torch.autograd.grad(la, q), wg):
-            close(a, b, rtol=2e-5)
+        all_grads_close(torch.autograd.grad(la, q), wg, w64, **tol)
         # the same maps as permuted views of convolution outputs (bs, na*no, ny, nx)
         convs = [x.permute(0, 1, 4, 2, 3).reshape(x.shape[0], -1, x.shape[2], x.shape[3]).contiguous() for x in d]
         views = [c.view(c.shape[0], 3, 85, c.shape[2], c.shape[3]).permute(0, 1, 3, 4, 2) for c in convs]
@@ -375,5 +389,4 @@ def test_sort_obj_iou_on_crowded_cells_vs_oracle():
         lc, ic, gc = crit.forward_backward(views, T(targets).cuda())
         close(lc, wl.detach())
         close(ic, wi)
-        for a, b in zip(gc, wg):
-            close(a, b, rtol=2e-5)
+        all_grads_close(gc, wg, w64, **tol)
