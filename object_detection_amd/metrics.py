@@ -65,26 +65,29 @@ def bbox_iou(box1, box2, x1y1x2y2=True, GIoU=False, DIoU=False, CIoU=False, eps=
     return _PairIoU.apply(box1, box2, 0, 1, x1y1x2y2, _mode(GIoU, DIoU, CIoU), eps)
 
 
-def _pairwise(name, a, b, width):
+def _pairwise(name, a, b, width, out=None):
     a = L.dev_f32(a, "box1").contiguous()
     b = L.dev_f32(b, "box2").contiguous()
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != width or b.shape[1] != width:
         raise RuntimeError(f"{name}: expected (N,{width}) and (M,{width}), got {tuple(a.shape)} and {tuple(b.shape)}")
-    out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    elif out.shape != (a.shape[0], b.shape[0]) or out.dtype != torch.float32 or out.device != a.device or not out.is_contiguous():
+        raise RuntimeError(f"{name}: out must be a contiguous fp32 ({a.shape[0]},{b.shape[0]}) matrix on {a.device}")
     with L.device_guard(a.device):
         L.check(getattr(L.lib(), "dh_" + name)(L.ptr(a), L.ptr(b), L.ptr(out), a.shape[0], b.shape[0], L.stream()),
                 "dh_" + name)
     return out
 
 
-def box_iou(box1, box2):
-    """(N,4) x (M,4) xyxy boxes -> (N,M) IoU matrix (metrics.py:242-264)."""
-    return _pairwise("box_iou", box1, box2, 4)
+def box_iou(box1, box2, out=None):
+    """(N,4) x (M,4) xyxy boxes -> (N,M) IoU matrix (metrics.py:242-264).  out: a matrix to fill instead of a new one."""
+    return _pairwise("box_iou", box1, box2, 4, out)
 
 
-def wh_iou(wh1, wh2):
+def wh_iou(wh1, wh2, out=None):
     """(N,2) x (M,2) width/height pairs -> (N,M) IoU matrix (metrics.py:291-296)."""
-    return _pairwise("wh_iou", wh1, wh2, 2)
+    return _pairwise("wh_iou", wh1, wh2, 2, out)
 
 
 def bbox_ioa(box1, box2, eps=1E-7):

@@ -37,6 +37,47 @@ def test_pairwise_large_vs_oracle():
         np.testing.assert_array_equal(box_iou(T(a).cuda(), T(b).cuda()).cpu().numpy(), ob.box_iou(T(a), T(b)).numpy())
 
 
+def test_pairwise_shapes_layouts_and_limits():
+    """Both store paths (four columns per lane when M % 4 == 0, one otherwise), tile edges on either side, degenerate
+    boxes (0/0 = NaN like the reference), a caller's output matrix, a misaligned view, wh_iou, and more row tiles than a
+    grid's y dimension holds (2.2 M rows)."""
+    from object_detection_amd.metrics import box_iou, wh_iou
+    rs = np.random.RandomState(14)
+
+    def boxes(n):
+        a = rs.uniform(0, 600, (n, 2)).astype(np.float32)
+        return np.concatenate([a, a + rs.uniform(0, 100, (n, 2)).astype(np.float32)], 1)
+    for n, m in ((31, 252), (32, 256), (33, 260), (129, 1028), (5, 1023), (97, 4), (2049, 1536)):
+        a, b = boxes(n), boxes(m)
+        a[0, 2:] = a[0, :2]                 # zero-area boxes: 0/0 against themselves
+        b[0] = a[0]
+        want = ob.box_iou(T(a), T(b)).numpy()
+        got = box_iou(T(a).cuda(), T(b).cuda())
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+        assert np.isnan(want[0, 0])
+        out = torch.full((n, m), -1.0, device="cuda")
+        assert box_iou(T(a).cuda(), T(b).cuda(), out=out) is out
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+        ww = ob.wh_iou(T(a[:, 2:]), T(b[:, 2:])).numpy()
+        np.testing.assert_array_equal(wh_iou(T(a).cuda()[:, 2:], T(b).cuda()[:, 2:]).cpu().numpy(), ww)
+    with pytest.raises(RuntimeError):
+        box_iou(T(boxes(3)).cuda(), T(boxes(4)).cuda(), out=torch.empty((4, 3), device="cuda"))
+    # the C entry on pointers that are only 4-byte aligned: the scalar path
+    from object_detection_amd import _lib as L
+    a, b = boxes(70), boxes(260)
+    pad_a, pad_b = torch.zeros(70 * 4 + 1, device="cuda"), torch.zeros(260 * 4 + 1, device="cuda")
+    pad_a[1:] = T(a).cuda().reshape(-1)
+    pad_b[1:] = T(b).cuda().reshape(-1)
+    out = torch.empty(70 * 260 + 1, device="cuda")
+    L.check(L.lib().dh_box_iou(L.c_void_p(pad_a.data_ptr() + 4), L.c_void_p(pad_b.data_ptr() + 4), L.c_void_p(out.data_ptr() + 4),
+                               70, 260, L.stream()), "dh_box_iou")
+    np.testing.assert_array_equal(out[1:].reshape(70, 260).cpu().numpy(), ob.box_iou(T(a), T(b)).numpy())
+    # 68 750 row tiles
+    a, b = boxes(2_200_000), boxes(8)
+    got = box_iou(T(a).cuda(), T(b).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(got, ob.box_iou(T(a), T(b)).numpy())
+
+
 def test_centernet_pool_decode_postprocess_golden(golden):
     from object_detection_amd import centernet as C
     g = golden("centernet")

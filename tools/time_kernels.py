@@ -36,7 +36,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--only", default="decode,loss,nms,centernet,iou")
+    ap.add_argument("--only", default="decode,loss,nms,centernet,iou,pairwise")
     args = ap.parse_args()
     only = set(args.only.split(","))
     dev = torch.device("cuda", 0)
@@ -102,6 +102,22 @@ def main():
                 us2 = timed(fb, args.iters)
                 print(f"bbox_iou {name:4s} f+b  n={n:9d} {us2:9.1f} us  (incl. the sum and the autograd engine)")
             del b1, b2
+    if "pairwise" in only:     # N x M IoU matrix (metrics.py:242-264): 16 B per box read, 4 B per pair written
+        from object_detection_amd.metrics import box_iou, wh_iou
+        g = torch.Generator(device=dev).manual_seed(6)
+        for n, m in ((100, 300), (300, 3000), (8192, 8192), (30000, 3000)):
+            xy1, xy2 = torch.rand((n, 2), generator=g, device=dev) * 600, torch.rand((m, 2), generator=g, device=dev) * 600
+            b1 = torch.cat((xy1, xy1 + torch.rand((n, 2), generator=g, device=dev) * 200 + 1), 1)
+            b2 = torch.cat((xy2, xy2 + torch.rand((m, 2), generator=g, device=dev) * 200 + 1), 1)
+            byts = 16.0 * (n + m) + 4.0 * n * m
+            us = timed(lambda: box_iou(b1, b2), args.iters)
+            print(f"box_iou {n:6d} x {m:6d} {us:9.1f} us  {byts / us / 1e3:8.1f} GB/s (16(N+M) + 4NM bytes; incl. the output allocation)")
+            out = torch.empty((n, m), device=dev)
+            us = timed(lambda: box_iou(b1, b2, out=out), args.iters)
+            print(f"box_iou {n:6d} x {m:6d} {us:9.1f} us  {byts / us / 1e3:8.1f} GB/s (into a caller's matrix)")
+            us = timed(lambda: wh_iou(b1[:, 2:], b2[:, 2:]), args.iters)
+            print(f"wh_iou  {n:6d} x {m:6d} {us:9.1f} us  {(8.0 * (n + m) + 4.0 * n * m) / us / 1e3:8.1f} GB/s")
+            del out
     if "centernet" in only:
         from object_detection_amd import centernet as CN
         B, W, H = bs, 160, 160
