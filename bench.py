@@ -7,7 +7,8 @@
 One "step" = one pass of the hot path over one batch of synthetic YOLOv5s head outputs that are
 already resident in HBM: bs 64 per GPU @ 640 px, 3 levels, 80 classes (25 200 anchors / image),
 640 targets.  Weak scaling: every rank owns its own 64 images (the path shards by image); the only
-collective is one 4-float all-reduce of the loss terms and positive count per step.
+collective is one all-reduce per step of the loss kernels' per-level sums and divisors (15 doubles), from which the loss
+terms of the whole batch are formed.
 Rank 0 prints ONE JSON line; `value` = images/s over all ranks.
 """
 import argparse
@@ -284,7 +285,7 @@ def main():
         else:
             loss, items = crit(p, targets)
             grads = torch.autograd.grad(loss, p)
-        return loss, items, grads, crit.last_stats       # [lbox, lobj, lcls, n_pos], written by the loss kernel
+        return loss, items, grads, crit.last_sums        # (nl, 5) float64 sums and divisors, written by the loss kernel
 
     host_s = {s: 0.0 for s in stages + ("finish",)}
     # Three HIP streams: decode on the main stream; the NMS chain (short, latency-bound kernels that read the decoded
@@ -306,7 +307,7 @@ def main():
     split = {"prev_stats": None, "reduced": None, "local_of_reduced": None}
 
     def reduce_stats(mine):
-        """all_reduce(SUM) of one step's [lbox, lobj, lcls, n_pos] on the current (side) stream."""
+        """all_reduce(SUM) of one step's per-level [sum(1-iou), sum cls, sum obj, rows, cells] on the current (side) stream."""
         if overlap:
             mine.record_stream(torch.cuda.current_stream())      # made on the main stream, read on this one
         mine = mine.clone() if backend == "nccl" else mine.cpu()   # (host tensor only in the gloo rehearsal)
@@ -345,7 +346,7 @@ def main():
         if early:
             torch.cuda.current_stream().wait_event(pos_done)
             loss, items, grads = crit.forward_backward(p, targets, positives=positives)
-            stats = crit.last_stats
+            stats = crit.last_sums
         else:
             loss, items, grads, stats = f_loss()
         if detail: marks[2].record()
@@ -456,14 +457,19 @@ def main():
         per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
         elapsed = max(float(t.item()) for t in every)          # the job is as slow as its slowest rank
         # the last step's reduced vector against the sum of what each rank put in (gathered outside the timed region)
-        local = split["local_of_reduced"].detach().to(cdev, torch.float32)
+        local = split["local_of_reduced"].detach().to(cdev, torch.float64).contiguous()
         parts = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(parts, local)
         want = torch.stack(parts).sum(0)
         got = split["reduced"].to(cdev)
-        collective_check = {"reduced": [round(float(v), 6) for v in got.tolist()],
-                            "sum_over_ranks": [round(float(v), 6) for v in want.tolist()],
-                            "ok": bool(torch.allclose(got, want, rtol=1e-6, atol=0.0))}
+        items_g = crit.items_from_sums(got)          # loss terms of the whole batch (sums over summed divisors)
+        items_l = crit.items_from_sums(local)
+        collective_check = {"reduced": [round(float(v), 6) for v in got.flatten().tolist()],
+                            "sum_over_ranks": [round(float(v), 6) for v in want.flatten().tolist()],
+                            "layout": "per level [sum(1-iou), sum class BCE, sum objectness BCE, assigned rows, cells]",
+                            "global_lbox_lobj_lcls_npos": [round(float(v), 6) for v in items_g.tolist()],
+                            "this_rank_lbox_lobj_lcls_npos": [round(float(v), 6) for v in items_l.tolist()],
+                            "ok": bool(torch.allclose(got, want, rtol=1e-9, atol=0.0))}
 
     # Untimed post-roll: the same steps for a couple of seconds.  The timed region above is a few dozen milliseconds,
     # which a once-per-second utilisation monitor never sees; this one it does, and its rate is reported beside `value`.
@@ -542,8 +548,9 @@ def main():
                 ("p10", "p50", "p90", "max", "argmax"), list(np.percentile(np.diff(step_wall), (10, 50, 90, 100))) +
                 [int(np.argmax(np.diff(step_wall))) * 1e-3])} if len(step_wall) > 2 else None,
             "ms_per_step_per_rank": [round(v, 4) for v in per_rank_ms],
-            "collective": ("one all_reduce(SUM) of [lbox, lobj, lcls, n_pos] per step over RCCL on the side stream; step i's "
-                           "vector travels while step i+1 is enqueued, the last step's inside the timed region") if dist_on else None,
+            "collective": ("one all_reduce(SUM) per step of the loss kernels' per-level sums and divisors (nl x 5 float64) over RCCL "
+                           "on the side stream; step i's block travels while step i+1 is enqueued, the last step's inside the "
+                           "timed region") if dist_on else None,
             "collective_check": collective_check,
             "pre_roll_steps": args.pre_roll,
             "sustained": sustained,

@@ -311,6 +311,12 @@ typedef struct dh_yolo_hyp {
  * (obj_logits[b][first_l + (a*ny+gj)*nx+gi] == p[l][b][a][gj][gi][4] bit for bit); the dense objectness
  * pass then reads it instead of the strided column. */
 size_t dh_yolo_loss_workspace(const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t cap);
+/* Byte offset inside that workspace of `double sums[nl][5]`, which every forward (and fused forward+backward) leaves there
+ * beside `out`: per level [sum of (1 - iou) over the assigned rows, sum of the class BCE terms, sum of the objectness BCE
+ * terms, assigned rows, cells] -- the numerators and divisors of the means of loss.py:136,149,155 before the division.
+ * Ranks of a data-parallel job (object_detection/yolov5/train.py:254-255) add these up (one all-reduce of 5*nl doubles) to
+ * form the means of the whole batch; the reference itself keeps per-rank means (train.py:331-332). */
+size_t dh_yolo_loss_sums_offset(const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t cap);
 int dh_yolo_loss_fwd(const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                      const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
                      int64_t cap, const dh_yolo_hyp* hyp, const float* obj_logits, float* out, void* workspace,
@@ -384,6 +390,16 @@ int dh_yolo_loss_dense(const float* const* p, const int* ny, const int* nx, int 
                        const float* tbox, const float* anch, const int64_t* tcls, const int* counts, int64_t cap,
                        const dh_yolo_hyp* hyp, const float* obj_logits, const float* grad_loss, float* const* grad_p,
                        float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* dh_yolo_loss_bwd (layout 0), dh_yolo_loss_bwd_conv (1) or dh_yolo_loss_bwd_conv_f16 (2: fp32 gradient, 3: fp16 gradient)
+ * with a factor per level on top of grad_loss: level_scale (device, 2*nl floats) holds for level l the factor on its box and
+ * class terms and the factor on its objectness term.  With factor = world size * this rank's divisor / the job's divisor
+ * (rows for box and class, cells for objectness; the job's divisors from the all-reduced sums at dh_yolo_loss_sums_offset)
+ * the gradients that DDP averages (object_detection/yolov5/train.py:254-255,331-332) are those of the loss normalised over
+ * the whole batch instead of per rank (loss.py:136,149,155). */
+int dh_yolo_loss_bwd_scaled(int layout, const void* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                            const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls, const int* counts,
+                            int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss, const float* level_scale,
+                            void* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream);
 
 
 /* N x M IoU of xyxy boxes, no eps (object_detection/yolov5/utils/metrics.py:242-264) and of

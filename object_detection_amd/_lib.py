@@ -85,6 +85,7 @@ SIGNATURES = {
     "dh_build_targets": (c_int, [c_void_p, c_i64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_double, c_i64, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_loss_workspace": (c_size_t, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64]),
+    "dh_yolo_loss_sums_offset": (c_size_t, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_i64]),
     "dh_yolo_loss_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -112,6 +113,8 @@ SIGNATURES = {
     "dh_yolo_loss_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
+    "dh_yolo_loss_bwd_scaled": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_box_iou": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "dh_wh_iou": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "dh_centernet_pool_nms": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),

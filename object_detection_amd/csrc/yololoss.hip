@@ -55,6 +55,7 @@ struct yl_params {
     long cap;
     float box, obj, cls, cls_pw, obj_pw, gamma, cp, cn, gr;
     int sort_iou;              // the best IoU among a cell's rows owns the cell instead of its last row (loss.py:140-142)
+    const float* level_scale;  // backward only, may be null: per level [factor on the box / class terms, factor on the objectness term]
 };
 
 #define FOCAL_ALPHA 0.25f   // default alpha of FocalLoss (loss.py:37); ComputeLoss never overrides it
@@ -315,7 +316,7 @@ template <int THREADS>
 __device__ __forceinline__ void yl_finalize(const yl_params& P, const int* __restrict__ counts, const float* __restrict__ iou_ws,
                                             const float* __restrict__ cls_ws, const double* __restrict__ partial,
                                             const int* __restrict__ invalid, float* __restrict__ out,
-                                            double (*red)[THREADS / 64])
+                                            double* __restrict__ sums, double (*red)[THREADS / 64])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned first_block = 0;
@@ -347,6 +348,9 @@ __device__ __forceinline__ void yl_finalize(const yl_params& P, const int* __res
             lcls += s_cls;
             lobj += s_obj * P.lvl[l].balance;                                                    // loss.py:156
             out[5 + l] = s_obj;
+            // the un-normalised sums and their divisors: what ranks add up to form the means of the whole batch
+            sums[5 * l + 0] = tb; sums[5 * l + 1] = P.nc > 1 ? tc : 0.0; sums[5 * l + 2] = to;
+            sums[5 * l + 3] = (double)n; sums[5 * l + 4] = (double)P.lvl[l].cells;
         }
         lbox *= P.box; lobj *= P.obj; lcls *= P.cls;                                             // loss.py:162-164
         out[0] = (lbox + lobj + lcls) * (float)P.bs;
@@ -359,10 +363,10 @@ __device__ __forceinline__ void yl_finalize(const yl_params& P, const int* __res
 __global__ void __launch_bounds__(FINAL_THREADS) k_yl_final(const yl_params P, const int* __restrict__ counts,
                                                             const float* __restrict__ iou_ws, const float* __restrict__ cls_ws,
                                                             const double* __restrict__ partial, const int* __restrict__ invalid,
-                                                            float* __restrict__ out)
+                                                            float* __restrict__ out, double* __restrict__ sums)
 {
     __shared__ double red[3 * DH_MAX_LEVELS][FINAL_THREADS / 64];
-    yl_finalize<FINAL_THREADS>(P, counts, iou_ws, cls_ws, partial, invalid, out, red);
+    yl_finalize<FINAL_THREADS>(P, counts, iou_ws, cls_ws, partial, invalid, out, sums, red);
 }
 
 // ------------------------------------------------------------------------------------ backward: dense pass
@@ -378,6 +382,7 @@ struct yl_final_args {
     const double* partial;
     const int* invalid;
     float* out;
+    double* sums;
 };
 
 template <int VEC, bool FINAL>
@@ -387,13 +392,13 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd(const yl_params P, const flo
 {
     if (FINAL && blockIdx.x == 0) {
         __shared__ double red[3 * DH_MAX_LEVELS][4];
-        yl_finalize<256>(P, F.counts, F.iou_ws, F.cls_ws, F.partial, F.invalid, F.out, red);
+        yl_finalize<256>(P, F.counts, F.iou_ws, F.cls_ws, F.partial, F.invalid, F.out, F.sums, red);
     }
     unsigned blk = blockIdx.x;
     const int l = level_of_block(P, blk);
     const yl_level& L = P.lvl[l];
     const float* __restrict__ d_l = dobj + L.cell_first;
-    const float scale = g_loss[0] * (float)P.bs * P.obj * L.balance / (float)L.cells;
+    const float scale = g_loss[0] * (float)P.bs * P.obj * L.balance / (float)L.cells * (P.level_scale ? P.level_scale[2 * l + 1] : 1.0f);
     const size_t total = (size_t)L.cells * P.no;
     const size_t nvec = total / VEC;
 #pragma unroll
@@ -434,7 +439,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, cons
 {
     if (FINAL && blockIdx.x == 0) {
         __shared__ double red[3 * DH_MAX_LEVELS][4];
-        yl_finalize<256>(P, F.counts, F.iou_ws, F.cls_ws, F.partial, F.invalid, F.out, red);
+        yl_finalize<256>(P, F.counts, F.iou_ws, F.cls_ws, F.partial, F.invalid, F.out, F.sums, red);
     }
     unsigned blk = blockIdx.x;
     const int l = level_of_block(P, blk);
@@ -444,7 +449,7 @@ __global__ void __launch_bounds__(256) k_yl_obj_bwd_conv(const yl_params P, cons
     const uint32_t ba = dh_div(blk, L.gchunks);
     const uint32_t e = ((blk - ba * L.gchunks.d) * 256 + threadIdx.x) * VEC;
     if (e >= span) return;
-    const float scale = g_loss[0] * (float)P.bs * P.obj * L.balance / (float)L.cells;
+    const float scale = g_loss[0] * (float)P.bs * P.obj * L.balance / (float)L.cells * (P.level_scale ? P.level_scale[2 * l + 1] : 1.0f);
     float o[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) o[k] = 0.0f;
@@ -531,7 +536,7 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
     const int head = owner[L.cell_first + R.cell];
     const int before_me = nxt_l[r];
 
-    const float up = g_loss[0] * (float)P.bs;
+    const float up = g_loss[0] * (float)P.bs * (P.level_scale ? P.level_scale[2 * l] : 1.0f);
     const float s0 = dh_sigmoid(x0), s1 = dh_sigmoid(x1), s2 = dh_sigmoid(x2), s3 = dh_sigmoid(x3);
     const float g_iou = -up * P.box / (float)n;                  // d lbox / d iou = -box/n  (lbox += mean(1 - iou))
     const float sc = up * P.cls / ((float)n * (float)P.nc);
@@ -600,7 +605,7 @@ __global__ void __launch_bounds__(256) k_yl_pos_bwd(const yl_params P, const lon
 }
 
 struct yl_ws {
-    size_t off_owner, off_iou, off_cls, off_partial, off_invalid, off_dobj, off_next, total;
+    size_t off_owner, off_iou, off_cls, off_partial, off_invalid, off_dobj, off_next, off_sums, total;
     long cells_total;
     unsigned obj_blocks;
 };
@@ -615,6 +620,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
     P.conv = conv ? 1 : 0;
     P.half = 0;
     P.half_grad = 0;
+    P.level_scale = nullptr;
     if (hyp) {
         P.box = hyp->box; P.obj = hyp->obj; P.cls = hyp->cls; P.cls_pw = hyp->cls_pw; P.obj_pw = hyp->obj_pw;
         P.gamma = hyp->fl_gamma; P.cp = hyp->cp; P.cn = hyp->cn; P.gr = hyp->gr;
@@ -662,6 +668,7 @@ bool make_params(const float* const* p, float* const* g, const int* ny, const in
     W.off_partial = o; o = up256(o + sizeof(double) * fwd_blocks);
     W.off_dobj = o; o = up256(o + sizeof(float) * (size_t)first);
     W.off_next = o; o = up256(o + sizeof(int) * (size_t)nl * (cap > 0 ? cap : 1));      // per row: the row before it in its cell's list
+    W.off_sums = o; o = up256(o + sizeof(double) * 5 * (size_t)nl);        // per level: sum(1-iou), sum class BCE, sum objectness BCE, rows, cells
     W.off_invalid = W.off_owner + sizeof(int) * (size_t)first;
     W.total = o;
     (void)blocks;
@@ -683,6 +690,14 @@ extern "C" size_t dh_yolo_loss_workspace(const int* ny, const int* nx, int nl, i
     yl_ws W;
     if (!make_params(nullptr, nullptr, ny, nx, nl, bs, na, nc, (long)cap, nullptr, false, P, W)) return 0;
     return W.total;
+}
+
+extern "C" size_t dh_yolo_loss_sums_offset(const int* ny, const int* nx, int nl, int bs, int na, int nc, int64_t cap)
+{
+    yl_params P;
+    yl_ws W;
+    if (!make_params(nullptr, nullptr, ny, nx, nl, bs, na, nc, (long)cap, nullptr, false, P, W)) return 0;
+    return W.off_sums;
 }
 
 namespace {
@@ -725,7 +740,8 @@ int launch_fwd(const yl_params& P, const yl_ws& W, char* ws, const int64_t* idx,
     else hipLaunchKernelGGL(k_yl_obj_fwd<false>, dim3(sum_blocks(P)), dim3(256), 0, st, P, owner, nxt, iou_ws, partial,
                             (float*)(ws + W.off_dobj), obj_logits);
     if (final)
-        hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(FINAL_THREADS), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out);
+        hipLaunchKernelGGL(k_yl_final, dim3(1), dim3(FINAL_THREADS), 0, st, P, counts, iou_ws, cls_ws, partial, invalid, out,
+                           (double*)(ws + W.off_sums));
     return dh_launch_status();
 }
 
@@ -747,7 +763,7 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
             P.lvl[l].blocks = (unsigned)((size_t)P.bs * P.na * chunks);
         }
         const float* dobj_c = (const float*)(ws + W.off_dobj);
-        const yl_final_args none_c = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const yl_final_args none_c = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         const dim3 grid_c(sum_blocks(P));
         if (P.half_grad) {
             if (F) {
@@ -787,7 +803,7 @@ int launch_bwd(yl_params& P, const yl_ws& W, const char* ws, const int64_t* idx,
     }
     const float* dobj = (const float*)(ws + W.off_dobj);
     const dh_fastdiv nod = dh_make_fastdiv((uint32_t)P.no);
-    const yl_final_args none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const yl_final_args none = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const dim3 grid(sum_blocks(P));
     if (F) {
         if (vec4) hipLaunchKernelGGL((k_yl_obj_bwd<4, true>), grid, dim3(256), 0, st, P, dobj, grad_loss, nod, *F);
@@ -817,7 +833,8 @@ static int loss_fwd(int conv, const float* const* p, const int* ny, const int* n
     for (int l = 0; l < nl; ++l) if (!p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
-    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && !dh_aligned16(tbox))) return DH_ERR_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && (!dh_aligned16(tbox) || (reinterpret_cast<uintptr_t>(anch) & 7u))))
+        return DH_ERR_ALIGN;
     return launch_fwd(P, W, (char*)workspace, idx, tbox, anch, tcls, counts, obj_logits, out, true, true, (hipStream_t)stream);
 }
 
@@ -842,7 +859,8 @@ extern "C" int dh_yolo_loss_fwd_conv(const float* const* conv, const int* ny, co
 static int loss_bwd(int conv, const float* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
                     const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
                     const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
-                    float* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream)
+                    float* const* grad_p, const void* workspace, size_t workspace_bytes, void* stream,
+                    const float* level_scale = nullptr)
 {
     yl_params P;
     yl_ws W;
@@ -850,9 +868,13 @@ static int loss_bwd(int conv, const float* const* p, const int* ny, const int* n
     if (!make_params(p, grad_p, ny, nx, nl, bs, na, nc, (long)cap, hyp, true, P, W, conv != 0)) return DH_ERR_ARG;
     P.half = conv >= 2;
     P.half_grad = conv == 3;
+    P.level_scale = level_scale;
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
+    // the mate rows of a shared cell are read as 16-byte / 8-byte vectors
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && (!dh_aligned16(tbox) || (reinterpret_cast<uintptr_t>(anch) & 7u))))
+        return DH_ERR_ALIGN;
     return launch_bwd(P, W, (const char*)workspace, idx, tbox, anch, tcls, counts, grad_loss, grad_p, nullptr, (hipStream_t)stream);
 }
 
@@ -891,7 +913,8 @@ static int loss_fwd_bwd(int conv, const float* targets, int64_t nt, const float*
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
-    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && !dh_aligned16(tbox))) return DH_ERR_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && (!dh_aligned16(tbox) || (reinterpret_cast<uintptr_t>(anch) & 7u))))
+        return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
     // 1 assignment; spare workgroups of that launch set the per-cell map and the counters behind it to -1
     int rc = dh_launch_build_targets(targets, nt, anchors, nl, na, ny, nx, anchor_t, cap, idx, tbox, anch, tcls, counts,
@@ -902,7 +925,7 @@ static int loss_fwd_bwd(int conv, const float* targets, int64_t nt, const float*
     if (rc != DH_OK) return rc;
     // 4 dense gradient, whose workgroup 0 also does the forward's reduction, 5 positives' gradient
     const yl_final_args F = {counts, (const float*)(ws + W.off_iou), (const float*)(ws + W.off_cls),
-                             (const double*)(ws + W.off_partial), (const int*)(ws + W.off_invalid), out};
+                             (const double*)(ws + W.off_partial), (const int*)(ws + W.off_invalid), out, (double*)(ws + W.off_sums)};
     return launch_bwd(Pb, Wb, ws, idx, tbox, anch, tcls, counts, grad_loss, grad_p, &F, (hipStream_t)stream);
 }
 
@@ -979,7 +1002,8 @@ extern "C" int dh_yolo_loss_positives(const float* targets, int64_t nt, const fl
     for (int l = 0; l < nl; ++l) if (!p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
-    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && !dh_aligned16(tbox))) return DH_ERR_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && (!dh_aligned16(tbox) || (reinterpret_cast<uintptr_t>(anch) & 7u))))
+        return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
     const int rc = dh_launch_build_targets(targets, nt, anchors, nl, na, ny, nx, anchor_t, cap, idx, tbox, anch, tcls, counts,
                                            assign_workspace, assign_workspace_bytes, ws + W.off_owner, W.off_iou - W.off_owner, stream);
@@ -1000,11 +1024,29 @@ extern "C" int dh_yolo_loss_dense(const float* const* p, const int* ny, const in
     for (int l = 0; l < nl; ++l) if (!p[l] || !grad_p[l]) return DH_ERR_ARG;
     if (cap > 0 && (!idx || !tbox || !anch || !tcls)) return DH_ERR_ARG;
     if (workspace_bytes < W.total) return DH_ERR_WORKSPACE;
-    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return DH_ERR_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255u) || (cap > 0 && (!dh_aligned16(tbox) || (reinterpret_cast<uintptr_t>(anch) & 7u))))
+        return DH_ERR_ALIGN;
     char* ws = (char*)workspace;
     const int rc = launch_fwd(P, W, ws, idx, tbox, anch, tcls, counts, obj_logits, out, false, false, (hipStream_t)stream, 2);
     if (rc != DH_OK) return rc;
     const yl_final_args F = {counts, (const float*)(ws + W.off_iou), (const float*)(ws + W.off_cls),
-                             (const double*)(ws + W.off_partial), (const int*)(ws + W.off_invalid), out};
+                             (const double*)(ws + W.off_partial), (const int*)(ws + W.off_invalid), out, (double*)(ws + W.off_sums)};
     return launch_bwd(Pb, Wb, ws, idx, tbox, anch, tcls, counts, grad_loss, grad_p, &F, (hipStream_t)stream);
+}
+
+// The backward of any of the layouts with a factor per level on top of the upstream gradient: level_scale[2*l] multiplies the
+// box and class terms of level l, level_scale[2*l + 1] its objectness term (device memory, nl pairs).  This is what turns the
+// per-rank normalisation of the reference (object_detection/yolov5/utils/loss.py:136,149,155: means over the rank's own rows
+// and cells) into the normalisation of the whole data-parallel batch: factor = world * local divisor / global divisor, with
+// the global divisors taken from the all-reduced sums the forward leaves at dh_yolo_loss_sums_offset.
+// layout: 0 maps (bs,na,ny,nx,no) fp32; 1 convolution layout fp32; 2 convolution layout fp16, fp32 gradient; 3 fp16 gradient.
+extern "C" int dh_yolo_loss_bwd_scaled(int layout, const void* const* p, const int* ny, const int* nx, int nl, int bs, int na, int nc,
+                                       const int64_t* idx, const float* tbox, const float* anch, const int64_t* tcls,
+                                       const int* counts, int64_t cap, const dh_yolo_hyp* hyp, const float* grad_loss,
+                                       const float* level_scale, void* const* grad_p, const void* workspace,
+                                       size_t workspace_bytes, void* stream)
+{
+    if (layout < 0 || layout > 3 || !level_scale) return DH_ERR_ARG;
+    return loss_bwd(layout, reinterpret_cast<const float* const*>(p), ny, nx, nl, bs, na, nc, idx, tbox, anch, tcls, counts, cap, hyp,
+                    grad_loss, reinterpret_cast<float* const*>(grad_p), workspace, workspace_bytes, stream, level_scale);
 }

@@ -33,6 +33,7 @@ class _Assignment:
         self.tcls = torch.empty((nl, rows), dtype=torch.int64, device=device)
         self.counts = torch.empty(nl, dtype=torch.int32, device=device)
         self.made_on = L._raw_stream(device.index)      # the stream the assignment kernel is enqueued on
+        self.sums = None                                # set by the loss forward: see _sums_view
 
     def borrow(self):
         """Called by a consumer: when it runs on another stream than the producer, the caching allocator has to know."""
@@ -96,6 +97,13 @@ def _check_levels(maps, assign, nc, na, conv):
     return bs
 
 
+def _sums_view(ws, assign, bs, na, nc, nl):
+    """The (nl, 5) float64 block the loss kernels leave in their workspace: per level [sum(1 - iou), sum class BCE,
+    sum objectness BCE, assigned rows, cells] -- the means of loss.py:136,149,155 before the division."""
+    off = L.lib().dh_yolo_loss_sums_offset(L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc, assign.cap)
+    return ws[off:off + 40 * nl].view(torch.float64).view(nl, 5)
+
+
 def _loss_fwd(assign, hyp, nc, maps, conv_na=0):
     """Launch the forward kernels; returns (out[5+nl], workspace) -- the workspace feeds the backward.
     conv_na = na: `maps` are convolution outputs (bs, na*no, ny, nx)."""
@@ -130,13 +138,15 @@ def _loss_fwd(assign, hyp, nc, maps, conv_na=0):
     return out, ws
 
 
-def _loss_bwd(assign, hyp, nc, maps, ws, g_loss, conv_na=0):
+def _loss_bwd(assign, hyp, nc, maps, ws, g_loss, conv_na=0, level_scale=None, half_grad=True):
     """Launch the backward kernels for upstream gradient g_loss (1 float on the device); returns grads
     (in the layout of `maps`: convolution layout when conv_na = na, and then in the maps' element type: fp16 convolution
-    outputs get the fp16 gradient their convolution's backward takes)."""
+    outputs get the fp16 gradient their convolution's backward takes, unless half_grad is False).
+    level_scale: (nl, 2) fp32 on the device, a factor per level on the box / class terms and on the objectness term."""
     nl = len(maps)
     bs, na = int(maps[0].shape[0]), conv_na or int(maps[0].shape[1])
-    half = bool(conv_na) and maps[0].dtype == torch.float16
+    half_in = bool(conv_na) and maps[0].dtype == torch.float16
+    half = half_in and half_grad
     grads = [torch.empty_like(x, dtype=torch.float16 if half else torch.float32) for x in maps]
     ptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in maps])
     gptrs = (L.c_void_p * nl)(*[x.data_ptr() for x in grads])
@@ -144,7 +154,12 @@ def _loss_bwd(assign, hyp, nc, maps, ws, g_loss, conv_na=0):
             L.ptr(assign.anch), L.ptr(assign.tcls), L.ptr(assign.counts), assign.cap, ctypes.byref(hyp), L.ptr(g_loss))
     tail = (gptrs, L.ptr(ws), ws.numel(), L.stream())
     with L.device_guard(maps[0].device):
-        if half:
+        if level_scale is not None:
+            layout = 0 if not conv_na else (3 if half else 2 if half_in else 1)
+            L.check(L.lib().dh_yolo_loss_bwd_scaled(layout, *head, L.ptr(level_scale), *tail), "dh_yolo_loss_bwd_scaled")
+        elif half_in and not half:
+            L.check(L.lib().dh_yolo_loss_bwd_conv_f16(*head, 0, *tail), "dh_yolo_loss_bwd_conv_f16")
+        elif half:
             L.check(L.lib().dh_yolo_loss_bwd_conv_f16(*head, 1, *tail), "dh_yolo_loss_bwd_conv_f16")
         elif conv_na:
             L.check(L.lib().dh_yolo_loss_bwd_conv(*head, *tail), "dh_yolo_loss_bwd_conv")
@@ -165,7 +180,7 @@ def _one(device):
 
 
 def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss, conv=False):
-    """Assignment, loss forward and backward through the single fused entry; returns (assignment, out, grads).
+    """Assignment, loss forward and backward through the single fused entry; returns (assignment, out, grads, sums).
     conv: `maps` are convolution outputs (bs, na*no, ny, nx) and so are the gradients."""
     tg = L.dev_f32(targets, "targets").contiguous()
     if tg.dim() != 2 or tg.shape[1] != 6:
@@ -195,14 +210,14 @@ def _loss_fused(shapes, targets, anchors, anchor_t, hyp, nc, maps, grad_loss, co
                 L.check(lib.dh_yolo_loss_fwd_bwd_conv_f16(*head, 0, *tail), "dh_yolo_loss_fwd_bwd_conv_f16")
             else:
                 L.check(lib.dh_yolo_loss_fwd_bwd_conv(*head, *tail), "dh_yolo_loss_fwd_bwd_conv")
-        return A, out, grads
+        return A, out, grads, _sums_view(ws, A, bs, na, nc, nl)
     logits = objectness_logits(maps)
     with L.device_guard(dev):
         L.check(lib.dh_yolo_loss_fwd_bwd(L.ptr(tg), A.nt, L.ptr(anc), float(anchor_t), ptrs, ny, nx, nl, bs, na, nc,
                                          L.ptr(A.idx), L.ptr(A.tbox), L.ptr(A.anch), L.ptr(A.tcls), L.ptr(A.counts), A.cap,
                                          ctypes.byref(hyp), L.ptr(logits), L.ptr(grad_loss), gptrs, L.ptr(out), L.ptr(aws),
                                          aws_bytes, L.ptr(ws), ws_bytes, L.stream()), "dh_yolo_loss_fwd_bwd")
-    return A, out, grads
+    return A, out, grads, _sums_view(ws, A, bs, na, nc, nl)
 
 
 class _Positives:
@@ -282,6 +297,7 @@ class _YoloLoss(torch.autograd.Function):
         if convs is not None:       # lazy maps: the kernels work on the convolution outputs themselves
             na = int(p[0].shape[1])
             out, ws = _loss_fwd(assign, hyp, nc, convs, conv_na=na)
+            assign.sums = _sums_view(ws, assign, int(convs[0].shape[0]), na, nc, len(convs))
             ctx.save_for_backward(*convs)
             ctx.state = (assign, hyp, nc, ws, [x.dtype for x in p])
             ctx.conv_na = na
@@ -291,6 +307,7 @@ class _YoloLoss(torch.autograd.Function):
         ctx.conv_na = 0
         maps = [L.dev_f32(x, f"p[{i}]").contiguous() for i, x in enumerate(p)]
         out, ws = _loss_fwd(assign, hyp, nc, maps)
+        assign.sums = _sums_view(ws, assign, int(maps[0].shape[0]), int(maps[0].shape[1]), nc, len(maps))
         ctx.save_for_backward(*maps)
         ctx.state = (assign, hyp, nc, ws, [x.dtype for x in p])
         loss, rest = out[0:1], out[1:]      # [lbox, lobj, lcls, n_pos, obji per level..., ignored rows]
@@ -322,6 +339,7 @@ class ComputeLoss:
         self.sort_obj_iou = False
         self.last_positive_counts = None
         self.last_stats = None
+        self.last_sums = None
         h = model.hyp
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
         det = model.module.model[-1] if is_parallel(model) else model.model[-1]
@@ -365,6 +383,7 @@ class ComputeLoss:
         self.last_positive_counts = assign.counts            # (nl,) int32 on the device: rows assigned per level
         loss, rest = _YoloLoss.apply(assign, self._hyp_struct(), int(self.nc), *p)
         self.last_stats = rest[0:4]                                             # [lbox, lobj, lcls, n_pos] on the device
+        self.last_sums = assign.sums                                            # (nl, 5) float64: the same before the divisions
         if self.autobalance:                                                    # loss.py:157-161 (host round trip)
             obji = rest[4:4 + self.nl].tolist()
             self.balance = [b * 0.9999 + 0.0001 / o for b, o in zip(self.balance, obji)]
@@ -391,10 +410,10 @@ class ComputeLoss:
         if convs is not None:       # lazy maps (see conv_layout_of): gradients come back as views of the same kind
             shapes = [(int(x.shape[2]), int(x.shape[3])) for x in p]
             g = _one(convs[0].device) if grad_loss is None else grad_loss
-            assign, out, grads = _loss_fused(shapes, targets, self.anchors, self.hyp['anchor_t'], self._hyp_struct(), int(self.nc),
-                                             [c.detach() for c in convs], g.reshape(1).float().contiguous(), conv=True)
+            assign, out, grads, sums = _loss_fused(shapes, targets, self.anchors, self.hyp['anchor_t'], self._hyp_struct(), int(self.nc),
+                                                   [c.detach() for c in convs], g.reshape(1).float().contiguous(), conv=True)
             self.last_positive_counts = assign.counts
-            self.last_stats = out[1:5]
+            self.last_stats, self.last_sums = out[1:5], sums
             self._autobalance_step(out)
             return out[0:1], out[1:4], _as_map_views(grads, int(p[0].shape[1]))
         maps = [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
@@ -403,19 +422,77 @@ class ComputeLoss:
         if grad_loss is None:
             grad_loss = _one(maps[0].device)
         grad_loss = grad_loss.reshape(1).float().contiguous()
+        bs, na, nl = int(maps[0].shape[0]), int(maps[0].shape[1]), len(maps)
         if positives is not None:       # assignment and positives' forward already enqueued (possibly on another stream)
             out, grads = _loss_dense(positives, int(self.nc), maps, grad_loss)
             assign = positives.assign
+            sums = _sums_view(positives.ws, assign, bs, na, int(self.nc), nl)
         elif assignment is not None:    # an assignment made earlier (possibly on another stream): the separate entries
             assign = self._assignment_for(shapes, targets, assignment)
             out, ws = _loss_fwd(assign, hyp, int(self.nc), maps)
             grads = _loss_bwd(assign, hyp, int(self.nc), maps, ws, grad_loss)
+            sums = _sums_view(ws, assign, bs, na, int(self.nc), nl)
         else:
-            assign, out, grads = _loss_fused(shapes, targets, self.anchors, self.hyp['anchor_t'], hyp, int(self.nc), maps, grad_loss)
+            assign, out, grads, sums = _loss_fused(shapes, targets, self.anchors, self.hyp['anchor_t'], hyp, int(self.nc), maps, grad_loss)
         self.last_positive_counts = assign.counts
-        self.last_stats = out[1:5]
+        self.last_stats, self.last_sums = out[1:5], sums
         self._autobalance_step(out)
         return out[0:1], out[1:4], grads
+
+    def items_from_sums(self, sums):
+        """[lbox, lobj, lcls, n_pos] (fp32, after the gains, as loss.py:162-167 returns them) from a (nl, 5) block of sums:
+        this rank's `last_sums`, or the sum of every rank's -- then the means are those of the whole data-parallel batch,
+        which a mean of per-rank means only equals when every rank holds the same number of assigned rows."""
+        s = sums.double()
+        n, cells = s[:, 3], s[:, 4]
+        has = n > 0
+        safe = torch.where(has, n, torch.ones_like(n))
+        lbox = torch.where(has, s[:, 0] / safe, torch.zeros_like(n)).sum() * float(self.hyp['box'])                # loss.py:136,162
+        lcls = torch.where(has, s[:, 1] / (safe * float(self.nc)), torch.zeros_like(n)).sum() * float(self.hyp['cls'])   # :149,164
+        bal = torch.tensor([float(b) for b in self.balance[:s.shape[0]]], dtype=torch.float64, device=s.device)
+        lobj = (s[:, 2] / cells * bal).sum() * float(self.hyp['obj'])                                              # :155-156,163
+        return torch.stack((lbox, lobj, lcls, n.sum())).float()
+
+    def forward_backward_global(self, p, targets, group=None, grad_loss=None):
+        """forward_backward with the loss normalised over the WHOLE data-parallel batch instead of per rank (opt-in; the
+        reference, and forward_backward, normalise per rank: loss.py:136 with train.py:331-332).
+
+        Every rank calls it on its own image shard.  Between forward and backward the per-level sums and divisors are
+        all-reduced (5*nl doubles, on the calling stream); the backward then scales the terms of level l by
+        world * local divisor / global divisor, so that the gradients DDP averages (after the caller's `loss *= WORLD_SIZE`,
+        train.py:331-332, which stays as it is) are those of the global loss.  Returns (loss[1], items[4], grads): items =
+        [lbox, lobj, lcls] of the whole batch and its number of assigned rows, loss = their sum * this rank's batch size --
+        what the reference's expression gives when its means run over all ranks.  Without a process group the result is
+        forward_backward's.  autobalance keeps following this rank's own objectness means."""
+        import torch.distributed as dist
+        convs = conv_layout_of(p)
+        maps = [c.detach() for c in convs] if convs is not None else [L.dev_f32(x.detach(), f"p[{i}]").contiguous() for i, x in enumerate(p)]
+        na = int(p[0].shape[1])
+        shapes = [(int(x.shape[2]), int(x.shape[3])) for x in p]
+        hyp, nc, nl, bs = self._hyp_struct(), int(self.nc), len(maps), int(maps[0].shape[0])
+        assign = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
+        out, ws = _loss_fwd(assign, hyp, nc, maps, conv_na=na if convs is not None else 0)
+        local = _sums_view(ws, assign, bs, na, nc, nl)
+        total, world = local.clone(), 1
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(group)
+            if dist.get_backend(group) == "gloo":         # host-side rehearsal backend
+                host = total.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                total = host.to(local.device)
+            else:
+                dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        ones = torch.ones_like(total[:, 3])
+        f_pos = torch.where(total[:, 3] > 0, world * local[:, 3] / torch.where(total[:, 3] > 0, total[:, 3], ones), ones)
+        f_obj = world * local[:, 4] / total[:, 4]
+        level_scale = torch.stack((f_pos, f_obj), 1).float().contiguous()
+        g = (_one(maps[0].device) if grad_loss is None else grad_loss).reshape(1).float().contiguous()
+        grads = _loss_bwd(assign, hyp, nc, maps, ws, g, conv_na=na if convs is not None else 0, level_scale=level_scale, half_grad=False)
+        items = self.items_from_sums(total)
+        self.last_positive_counts, self.last_stats, self.last_sums = assign.counts, out[1:5], local
+        self._autobalance_step(out)
+        loss = (items[0:3].sum() * bs).reshape(1)
+        return loss, items, (_as_map_views(grads, na) if convs is not None else grads)
 
     def _autobalance_step(self, out):
         """loss.py:157-161: the balance weights follow the per-level objectness means (one host round trip, like the

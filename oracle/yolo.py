@@ -142,9 +142,17 @@ class YoloLossOracle:
         self.gr = 1.0
         self.sort_obj_iou = False
 
-    def _bce(self, logits, target, pos_weight):
+    def _bce(self, logits, target, pos_weight, sums=None):
         pw = torch.tensor([pos_weight], dtype=logits.dtype)
         g = self.hyp["fl_gamma"]
+        if sums is not None:      # the sum of the same terms in double precision, for the data-parallel checks
+            with torch.no_grad():
+                e = F.binary_cross_entropy_with_logits(logits.double(), target.double(), pos_weight=pw.double(), reduction="none")
+                if g > 0:
+                    prob = torch.sigmoid(logits.double())
+                    p_t = target * prob + (1 - target) * (1 - prob)
+                    e = e * ((target * 0.25 + (1 - target) * 0.75) * (1.0 - p_t) ** g)
+                sums.append(float(e.sum()))
         if g > 0:
             return _focal(F.binary_cross_entropy_with_logits(logits, target, pos_weight=pw, reduction="none"),
                           logits, target, g)
@@ -160,6 +168,7 @@ class YoloLossOracle:
         dt = p[0].dtype
         lcls, lbox, lobj = torch.zeros(1, dtype=dt), torch.zeros(1, dtype=dt), torch.zeros(1, dtype=dt)
         assigned = self.targets_for(p, targets)
+        self.last_sums = torch.zeros(len(p), 5, dtype=torch.float64)   # per level: sum(1-iou), sum cls BCE, sum obj BCE, rows, cells
         for lvl, pi in enumerate(p):
             t = assigned[lvl]
             b, a, gj, gi = (torch.from_numpy(t[k]) for k in ("b", "a", "gj", "gi"))
@@ -172,6 +181,7 @@ class YoloLossOracle:
                 pbox = torch.cat((pxy, pwh), 1)
                 iou = bbox_iou_yolo(pbox.T, torch.from_numpy(t["tbox"]).to(dt), x1y1x2y2=False, CIoU=True)
                 lbox = lbox + (1.0 - iou).mean()                                       # loss.py:136
+                self.last_sums[lvl, 0] = float((1.0 - iou.detach().double()).sum())
                 score_iou = iou.detach().clamp(0).type(tobj.dtype)
                 if self.sort_obj_iou:                                                  # loss.py:140-142
                     order = torch.argsort(score_iou)
@@ -180,8 +190,12 @@ class YoloLossOracle:
                 if self.nc > 1:                                                        # loss.py:146-149
                     tc = torch.full_like(ps[:, 5:], self.cn)
                     tc[range(n), torch.from_numpy(t["tcls"])] = self.cp
-                    lcls = lcls + self._bce(ps[:, 5:], tc, self.hyp["cls_pw"])
-            obji = self._bce(pi[..., 4], tobj, self.hyp["obj_pw"])                     # loss.py:155
+                    acc = []
+                    lcls = lcls + self._bce(ps[:, 5:], tc, self.hyp["cls_pw"], acc)
+                    self.last_sums[lvl, 1] = acc[0]
+            acc = []
+            obji = self._bce(pi[..., 4], tobj, self.hyp["obj_pw"], acc)                # loss.py:155
+            self.last_sums[lvl, 2], self.last_sums[lvl, 3], self.last_sums[lvl, 4] = acc[0], n, tobj.numel()
             lobj = lobj + obji * self.balance[lvl]
             if self.autobalance:
                 self.balance[lvl] = self.balance[lvl] * 0.9999 + 0.0001 / obji.detach().item()

@@ -57,6 +57,71 @@ def test_two_rank_all_reduce_and_sharding(tmp_path):
     assert sum(len(a["b"]) for a in glob) == int(r[0]["stats"][3])
 
 
+def _sum_worker(rank, world, port, out_dir):
+    """Rank `rank` evaluates the oracle on its image shard and puts the per-level sums through the product's reduction."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from object_detection_amd.dist import all_reduce_loss_stats, all_reduce_loss_sums, shard_targets
+    levels, targets, bs = _unequal_batch()
+    per = bs // world
+    mine = shard_targets(torch.from_numpy(targets), rank, world, bs)
+    oracle = oy.YoloLossOracle(oy.grid_anchors(), dict(oy.HYP_SCRATCH), nc=20)
+    _, items = oracle([torch.from_numpy(x[rank * per:(rank + 1) * per]) for x in levels], mine)
+    total = all_reduce_loss_sums(oracle.last_sums)
+    means = all_reduce_loss_stats(items, torch.tensor([int(v) for v in oracle.last_sums[:, 3]], dtype=torch.int32))
+    torch.save({"total": total, "local": oracle.last_sums, "mean_of_means": means}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _unequal_batch():
+    """bs 8 at 128 px, 20 classes; 56 of the 64 targets fall on the first rank's four images."""
+    from tests._synth import synth_head
+    rs = np.random.RandomState(78)
+    bs = 8
+    levels = synth_head(rs, bs, 128, 20)
+    targets = synth_targets(rs, 64, bs, 20)
+    targets[:56, 0] = rs.randint(0, 4, 56)
+    targets[56:, 0] = rs.randint(4, 8, 8)
+    return levels, targets[np.argsort(targets[:, 0], kind="stable")], bs
+
+
+def test_global_means_from_reduced_sums_with_unequal_positives(tmp_path):
+    """The sum-form exchange: per-level [sum(1-iou), sum cls, sum obj, rows, cells] added over two ranks and divided once
+    give the loss terms of the unsharded batch (1e-6), although the ranks hold very different numbers of assigned rows --
+    where the mean of the per-rank means is off by percents."""
+    from object_detection_amd.yolo_loss import ComputeLoss
+    world = 2
+    mp.spawn(_sum_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"s{k}.pt") for k in range(world)]
+    assert torch.equal(r[0]["total"], r[1]["total"])
+    torch.testing.assert_close(r[0]["total"], r[0]["local"] + r[1]["local"], rtol=1e-12, atol=0)
+    n0, n1 = float(r[0]["local"][:, 3].sum()), float(r[1]["local"][:, 3].sum())
+    assert n0 > 4 * n1 > 0
+
+    levels, targets, bs = _unequal_batch()
+    whole = oy.YoloLossOracle(oy.grid_anchors(), dict(oy.HYP_SCRATCH), nc=20)
+    _, want = whole([torch.from_numpy(x) for x in levels], torch.from_numpy(targets))
+    torch.testing.assert_close(whole.last_sums, r[0]["total"], rtol=1e-9, atol=1e-9)
+
+    class Det:
+        na, nc, nl, anchors, stride = 3, 20, 3, oy.grid_anchors(), torch.tensor(oy.YOLOV5S_STRIDES)
+
+    class M(torch.nn.Module):
+        pass
+    m = M()
+    m.model, m.hyp = [Det()], dict(oy.HYP_SCRATCH)
+    got = ComputeLoss(m).items_from_sums(r[0]["total"])
+    torch.testing.assert_close(got[:3], want, rtol=1e-6, atol=0)
+    assert float(got[3]) == n0 + n1
+    # the mean of the per-rank means is a different number here (box and class terms: the divisors differ per rank)
+    mom = r[0]["mean_of_means"]
+    assert abs(float(mom[0]) - float(want[0])) > 1e-3 * float(want[0])
+    assert abs(float(mom[2]) - float(want[2])) > 1e-3 * float(want[2])
+    torch.testing.assert_close(mom[1], want[1], rtol=1e-5, atol=0)      # objectness: equal cell counts, so the means agree
+
+
 def test_single_process_passthrough():
     from object_detection_amd.dist import all_reduce_loss_stats
     out = all_reduce_loss_stats(torch.tensor([1.0, 2.0, 3.0]), torch.tensor([4, 5, 6], dtype=torch.int32))
