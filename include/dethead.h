@@ -58,6 +58,17 @@ int dh_centernet_box_loss_bwd(const float* pred_xy, int64_t pred_xy_bstride, con
                               int add_coords, double eps, const float* fwd_out2, const float* grad_out,
                               float* grad_xy, int64_t grad_xy_bstride, float* grad_wh, int64_t grad_wh_bstride,
                               void* stream);
+/* The two calls above as one sequence of two launches, for a training step that takes the gradients directly
+ * (`losses["box"] = criterion["box"](...)` followed by backward(), object_detection/detectors/centernet/loss.py:24-28 and
+ * object_detection/train_loop.py:296-311): the gradient pass reduces the forward's partial sums itself, so no reduction
+ * launch sits between them.  grad_out: upstream gradient of the loss (1 float, device) or NULL for 1; out2, gradients and
+ * workspace as above.  Values and gradients equal the separate calls bit for bit. */
+int dh_centernet_box_loss_fwd_bwd(const float* pred_xy, int64_t pred_xy_bstride, const float* pred_wh,
+                                  int64_t pred_wh_bstride, const float* tgt_xy, int64_t tgt_xy_bstride,
+                                  const float* tgt_wh, int64_t tgt_wh_bstride, const float* mask, int B, int W, int H,
+                                  int add_coords, double eps, const float* grad_out, float* out2, float* grad_xy,
+                                  int64_t grad_xy_bstride, float* grad_wh, int64_t grad_wh_bstride, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 
 /* Detect.forward inference decode of all levels into (bs, sum na*ny*nx, no)
  * (object_detection/yolov5/models/yolo.py:56-70,72-81).  level_ptrs/ny/nx/strides are host

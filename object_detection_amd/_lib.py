@@ -31,6 +31,9 @@ SIGNATURES = {
     "dh_centernet_box_loss_bwd": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
                                           c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
                                           c_void_p, c_i64, c_void_p, c_i64, c_void_p]),
+    "dh_centernet_box_loss_fwd_bwd": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64,
+                                              c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+                                              c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_size_t, c_void_p]),
     "dh_yolo_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "dh_yolo_decode_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .loss import IoULossWithMask, masked_ciou_loss
+from .loss import IoULossWithMask, masked_ciou_loss, masked_ciou_loss_forward_backward
 
 
 def pool_nms(heat, kernel=3):
@@ -177,6 +177,15 @@ def offset_to_coord(pred):
     ix = torch.arange(dim_w, device=p.device, dtype=torch.float32).view(1, 1, dim_w, 1)
     iy = torch.arange(dim_h, device=p.device, dtype=torch.float32).view(1, 1, 1, dim_h)
     return p + torch.cat([ix.expand(1, 1, dim_w, dim_h), iy.expand(1, 1, dim_w, dim_h)], dim=1)
+
+
+def box_loss_forward_backward(pred_offset, pred_size, label_offset, label_size, mask, grad_loss=None):
+    """The box branch of compute_losses (object_detection/detectors/centernet/loss.py:22-28 with criterion["box"] =
+    IoULossWithMask) and its gradients in one call of two launches, without the autograd engine:
+    (loss, d loss / d pred_offset, d loss / d pred_size).  The coordinate add of offset_to_coord, the mask multiply, CIoU,
+    the reduction and the gradient never leave the kernels; values equal compute_losses + backward() bit for bit."""
+    return masked_ciou_loss_forward_backward(pred_offset, pred_size, label_offset, label_size, mask, add_coords=True,
+                                             grad_loss=grad_loss)
 
 
 def compute_losses(pred, labels, criterion, losses):

@@ -171,12 +171,18 @@ __global__ void __launch_bounds__(256) k_cn_loss_fwd(cn_maps mp, int W, dh_fastd
     }
 }
 
-// out[0] = 1 - sum_ciou / (4*sum_mask + 1e-4)  (object_detection/loss.py:112-115); out[1] = that divisor
-__global__ void __launch_bounds__(256) k_cn_loss_final(const double* __restrict__ partial, int nblocks, float* __restrict__ out)
+// The reduction of the forward's per-workgroup partial sums by the 256 threads of one workgroup (all of them call it):
+// returns the divisor 4*sum_mask + 1e-4 of object_detection/loss.py:112-115 to every thread and, when `out` is given, thread
+// 0 writes out[0] = 1 - sum_ciou / divisor and out[1] = divisor.  One order of additions wherever it runs, so the
+// reduction launch and the workgroups of the fused backward arrive at the same bits.
+__device__ __forceinline__ float cn_reduce(const double* __restrict__ partial, int nblocks, float* __restrict__ out, double (*red)[4],
+                                           float* __restrict__ shared_denom)
 {
     double s = 0.0, m = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) { s += partial[2 * i]; m += partial[2 * i + 1]; }
-    __shared__ double red[2][4];
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        if (out) s += partial[2 * i];
+        m += partial[2 * i + 1];
+    }
     s = dh_wave_sum_d(s);
     m = dh_wave_sum_d(m);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -186,9 +192,19 @@ __global__ void __launch_bounds__(256) k_cn_loss_final(const double* __restrict_
         const float sum_iou = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
         const float sum_m4 = (float)(4.0 * (red[1][0] + red[1][1] + red[1][2] + red[1][3]));
         const float denom = sum_m4 + 1e-4f;
-        out[0] = 1.0f - __fdiv_rn(sum_iou, denom);
-        out[1] = denom;
+        if (out) { out[0] = 1.0f - __fdiv_rn(sum_iou, denom); out[1] = denom; }
+        *shared_denom = denom;
     }
+    __syncthreads();
+    return *shared_denom;
+}
+
+// out[0] = 1 - sum_ciou / (4*sum_mask + 1e-4)  (object_detection/loss.py:112-115); out[1] = that divisor
+__global__ void __launch_bounds__(256) k_cn_loss_final(const double* __restrict__ partial, int nblocks, float* __restrict__ out)
+{
+    __shared__ double red[2][4];
+    __shared__ float denom;
+    cn_reduce(partial, nblocks, out, red, &denom);
 }
 
 struct cn_grads {
@@ -197,14 +213,26 @@ struct cn_grads {
 };
 
 // d loss / d pred = -(g_out / denom) * dCIoU/d(pred*mask) * mask
+// FUSED: the forward's partial sums have not been reduced yet.  Every workgroup adds up the mask partials itself (a few KB
+// from L2, the same additions in the same order everywhere) instead of waiting for a reduction launch, and workgroup (0,0)
+// also writes the loss value and the divisor to fwd_out.  g_out may then be null: upstream gradient 1.
+template <bool FUSED>
 __global__ void __launch_bounds__(256) k_cn_loss_bwd(cn_maps mp, cn_grads gr, int W, dh_fastdiv Hd, int add_coords,
-                                                     float eps, float ope, const float* __restrict__ fwd_out,
-                                                     const float* __restrict__ g_out)
+                                                     float eps, float ope, float* __restrict__ fwd_out,
+                                                     const float* __restrict__ g_out, const double* __restrict__ partial, int nblocks)
 {
     const long plane = (long)W * Hd.d;
     const long vec_per_img = plane / 4;
     const int b = blockIdx.y;
-    const float scale = -__fdiv_rn(g_out[0], fwd_out[1]);
+    float denom;
+    if (FUSED) {
+        __shared__ double red[2][4];
+        __shared__ float sh_denom;
+        denom = cn_reduce(partial, nblocks, (blockIdx.x == 0 && blockIdx.y == 0) ? fwd_out : nullptr, red, &sh_denom);
+    } else {
+        denom = fwd_out[1];
+    }
+    const float scale = -__fdiv_rn(g_out ? g_out[0] : 1.0f, denom);
     for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < vec_per_img; v += (long)gridDim.x * blockDim.x) {
         const long cell = v * 4;
         float px[4], py[4], pw[4], ph[4], tx[4], ty[4], tw[4], th[4], m[4];
@@ -334,7 +362,34 @@ extern "C" int dh_centernet_box_loss_bwd(const float* pred_xy, int64_t pred_xy_b
     if (grad_xy_bstride % 4 || grad_wh_bstride % 4) return DH_ERR_ARG;
     if (!cn_aligned(mp) || !dh_aligned16(grad_xy) || !dh_aligned16(grad_wh)) return DH_ERR_ALIGN;
     const cn_grads gr = {grad_xy, grad_xy_bstride, grad_wh, grad_wh_bstride};
-    hipLaunchKernelGGL(k_cn_loss_bwd, dim3(cn_grid_x(B, W, H), B), dim3(256), 0, (hipStream_t)stream, mp, gr, W,
-                       dh_make_fastdiv((uint32_t)H), add_coords, (float)eps, (float)(1.0 + eps), fwd_out2, grad_out);
+    hipLaunchKernelGGL(k_cn_loss_bwd<false>, dim3(cn_grid_x(B, W, H), B), dim3(256), 0, (hipStream_t)stream, mp, gr, W,
+                       dh_make_fastdiv((uint32_t)H), add_coords, (float)eps, (float)(1.0 + eps), const_cast<float*>(fwd_out2), grad_out,
+                       (const double*)nullptr, 0);
+    return dh_launch_status();
+}
+
+// Forward, reduction and gradient in two launches: the forward's partial sums, then the gradient pass, whose workgroups
+// reduce the partials themselves (no reduction launch, no second stream round trip).  Same values as the two entries above.
+extern "C" int dh_centernet_box_loss_fwd_bwd(const float* pred_xy, int64_t pred_xy_bstride, const float* pred_wh,
+                                             int64_t pred_wh_bstride, const float* tgt_xy, int64_t tgt_xy_bstride,
+                                             const float* tgt_wh, int64_t tgt_wh_bstride, const float* mask, int B, int W,
+                                             int H, int add_coords, double eps, const float* grad_out, float* out2,
+                                             float* grad_xy, int64_t grad_xy_bstride, float* grad_wh, int64_t grad_wh_bstride,
+                                             void* workspace, size_t workspace_bytes, void* stream)
+{
+    const cn_maps mp = {pred_xy, pred_xy_bstride, pred_wh, pred_wh_bstride, tgt_xy, tgt_xy_bstride, tgt_wh, tgt_wh_bstride, mask};
+    if (!cn_args_ok(mp, B, W, H) || !out2 || !workspace || !grad_xy || !grad_wh) return DH_ERR_ARG;
+    if (grad_xy_bstride % 4 || grad_wh_bstride % 4) return DH_ERR_ARG;
+    if (!cn_aligned(mp) || !dh_aligned16(grad_xy) || !dh_aligned16(grad_wh) || (reinterpret_cast<uintptr_t>(workspace) & 7u))
+        return DH_ERR_ALIGN;
+    if (workspace_bytes < dh_centernet_box_loss_workspace(B, W, H)) return DH_ERR_WORKSPACE;
+    const int gx = cn_grid_x(B, W, H);
+    const dh_fastdiv Hd = dh_make_fastdiv((uint32_t)H);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_cn_loss_fwd, dim3(gx, B), dim3(256), 0, st, mp, W, Hd, add_coords, (float)eps, (float)(1.0 + eps),
+                       (double*)workspace);
+    const cn_grads gr = {grad_xy, grad_xy_bstride, grad_wh, grad_wh_bstride};
+    hipLaunchKernelGGL(k_cn_loss_bwd<true>, dim3(gx, B), dim3(256), 0, st, mp, gr, W, Hd, add_coords, (float)eps, (float)(1.0 + eps),
+                       out2, grad_out, (const double*)workspace, gx * B);
     return dh_launch_status();
 }

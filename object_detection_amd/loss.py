@@ -113,6 +113,34 @@ def masked_ciou_loss(pred_xy, pred_wh, tgt_xy, tgt_wh, mask, add_coords=False):
     return _MaskedCIoULossPlanes.apply(pred_xy, pred_wh, tgt_xy, tgt_wh, mask, add_coords)
 
 
+def _loss_forward_backward(pxy, pwh, txy, twh, m, add_coords, grad_loss, gxy, gwh):
+    B, W, H = _check_planes(pxy, pwh, txy, twh, m)
+    lib = L.lib()
+    ws_bytes = lib.dh_centernet_box_loss_workspace(B, W, H)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pxy.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=pxy.device)
+    g = None if grad_loss is None else grad_loss.reshape(1).float().contiguous()
+    with L.device_guard(pxy.device):
+        L.check(lib.dh_centernet_box_loss_fwd_bwd(L.ptr(pxy), pxy.stride(0), L.ptr(pwh), pwh.stride(0), L.ptr(txy), txy.stride(0),
+                                                  L.ptr(twh), twh.stride(0), L.ptr(m), B, W, H, int(add_coords), _EPS, L.ptr(g),
+                                                  L.ptr(out2), L.ptr(gxy), gxy.stride(0), L.ptr(gwh), gwh.stride(0), L.ptr(ws),
+                                                  ws_bytes, L.stream()), "dh_centernet_box_loss_fwd_bwd")
+    return out2[0]
+
+
+def masked_ciou_loss_forward_backward(pred_xy, pred_wh, tgt_xy, tgt_wh, mask, add_coords=False, grad_loss=None):
+    """masked_ciou_loss and its gradients in one call of two launches, without the autograd engine:
+    (loss, d loss / d pred_xy, d loss / d pred_wh).  grad_loss: upstream gradient of the loss (1 float on the device,
+    default 1).  Same values, bit for bit, as the loss followed by backward()."""
+    B, _, W, H = pred_xy.shape
+    pxy, pwh, txy, twh = (_plane_view(L.dev_f32(t.detach(), n), H, W) for t, n in (
+        (pred_xy, "pred_xy"), (pred_wh, "pred_wh"), (tgt_xy, "tgt_xy"), (tgt_wh, "tgt_wh")))
+    m = L.dev_f32(mask, "mask").contiguous()
+    gxy = torch.empty((B, 2, W, H), dtype=torch.float32, device=pxy.device)
+    gwh = torch.empty((B, 2, W, H), dtype=torch.float32, device=pxy.device)
+    return _loss_forward_backward(pxy, pwh, txy, twh, m, add_coords, grad_loss, gxy, gwh), gxy, gwh
+
+
 class IoULossWithMask(nn.Module):
     """loss.py:102-115.  As in the reference the constructor flags are stored but CIoU is always used."""
 
@@ -124,6 +152,19 @@ class IoULossWithMask(nn.Module):
 
     def forward(self, pred, target, mask):
         return _MaskedCIoULossPacked.apply(pred, target, mask)
+
+    def forward_backward(self, pred, target, mask, grad_loss=None):
+        """forward(pred, target, mask) and d loss / d pred in one call of two launches, without the autograd engine (a
+        training step's criterion["box"](...) + backward(), object_detection/detectors/centernet/loss.py:24-28):
+        (loss, gradient of pred's shape).  Same values, bit for bit."""
+        p = L.dev_f32(pred.detach(), "pred").contiguous()
+        t = L.dev_f32(target, "target").contiguous()
+        m = L.dev_f32(mask, "mask").contiguous()
+        if p.dim() != 4 or p.shape[1] != 4 or t.shape != p.shape:
+            raise RuntimeError(f"IoULossWithMask: expected (B,4,W,H) pred/target, got {tuple(pred.shape)} / {tuple(target.shape)}")
+        grad = torch.empty_like(p)
+        loss = _loss_forward_backward(p[:, 0:2], p[:, 2:4], t[:, 0:2], t[:, 2:4], m, False, grad_loss, grad[:, 0:2], grad[:, 2:4])
+        return loss, grad
 
 
 class _FocalLoss(torch.autograd.Function):

@@ -163,6 +163,10 @@ def main():
             torch.autograd.grad(v, [ps, po])
         us2 = timed(fb2, args.iters)
         print(f"centernet loss f+b sparse {us2:9.1f} us  bwd ~{us2 - us:8.1f} us {52.0 * cells / (us2 - us) / 1e3:8.1f} GB/s (52 B/cell)")
+        from object_detection_amd.centernet import box_loss_forward_backward
+        us3 = timed(lambda: box_loss_forward_backward(po, ps, lo, ls, mask), args.iters)
+        print(f"centernet loss f+b sparse, fused entry (two launches, no autograd) {us3:9.1f} us  {88.0 * cells / us3 / 1e3:8.1f} GB/s "
+              f"(36 B/cell forward + 52 B/cell gradient pass)")
         dense = torch.ones_like(mask)
         us = timed(lambda: masked_ciou_loss(po, ps, lo + 1, ls + 1, dense, add_coords=True), args.iters)
         print(f"centernet loss fwd dense  {us:9.1f} us  {36.0 * cells / us / 1e3:8.1f} GB/s (36 B/cell)")
