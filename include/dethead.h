@@ -266,7 +266,9 @@ int dh_nms_plain(const float* boxes, const float* scores, int64_t n, double iou_
  * the library runs on holds its own copy until the process ends).  n <= 32768, larger inputs return DH_ERR_TOO_LARGE (-5).
  * The call allocates and frees nothing.  All calls on one GPU share that array: calls that overlap on one GPU (two
  * streams, two threads) race; serialise them.  The first call on a device looks the array's address up
- * (hipGetSymbolAddress), so make one call outside graph capture before capturing. */
+ * (hipGetSymbolAddress), so make one call outside graph capture before capturing.  `stream` must belong to the device
+ * that is current when the call is made (every GPU has its own copy of the array): a stream of another device returns
+ * DH_ERR_ARG. */
 int dh_nms_plain_noalloc(const float* boxes, const float* scores, int64_t n, double iou_thres, int64_t* keep_index,
                          int* keep_count, void* stream);
 

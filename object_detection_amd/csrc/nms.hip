@@ -2970,6 +2970,12 @@ extern "C" int dh_nms_plain_noalloc(const float* boxes, const float* scores, int
     if (!boxes || !scores || !keep_index) return DH_ERR_ARG;
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) return DH_ERR_ARG;
+    // Every GPU holds its own copy of the array, and the launches below go to the current device: a stream that lives on
+    // another GPU would pair that GPU's kernels with this GPU's array.  Refused instead of guessed at.
+    if (st) {
+        hipDevice_t of_stream = -1;
+        if (hipStreamGetDevice(st, &of_stream) == hipSuccess && (int)of_stream != dev) return DH_ERR_ARG;
+    }
     void* ws = nullptr;
     {
         std::lock_guard<std::mutex> hold(g_scratch_lock);

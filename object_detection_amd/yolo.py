@@ -77,12 +77,36 @@ def objectness_logits(maps):
     return _borrow(hit[1], hit[2])
 
 
+_STRIDE_VALUES = {}
+
+
+def _stride_values(stride):
+    """The strides as a tuple of host floats.  A model that has been moved to the device holds Detect.stride there
+    (Model._apply, yolo.py:231-236): reading it is a blocking device-to-host copy, which a steady loop should not pay per
+    call and which is illegal under stream capture.  A device tensor is therefore read once and remembered by identity
+    (the very object, at its address and version); host tensors and sequences are read as they are."""
+    if not isinstance(stride, torch.Tensor):
+        return tuple(float(v) for v in stride)
+    if not stride.is_cuda:
+        return tuple(float(v) for v in stride.tolist())
+    key = (stride.data_ptr(), stride._version, tuple(stride.shape))
+    hit = _STRIDE_VALUES.get(key)
+    if hit is not None and hit[0]() is stride:
+        return hit[1]
+    vals = tuple(float(v) for v in stride.tolist())
+    if len(_STRIDE_VALUES) > 64:
+        _STRIDE_VALUES.clear()
+    _STRIDE_VALUES[key] = (weakref.ref(stride), vals)
+    return vals
+
+
 def _anchor_pixels(anchors, stride, half_model=False):
     """Host copies of anchor_grid (= anchors[i] * stride[i], yolo.py:79, formed in fp32 like the reference)
     and of the strides; cached per anchors tensor (the very object, at its version) and stride values, so the
-    steady state does no device-to-host copy.  half_model: the anchor_grid of a half-precision model (yolo.py:79-80) --
-    the fp16 anchors buffer times the stride, rounded to fp16, then .float()."""
-    svals = tuple(float(v) for v in (stride.tolist() if isinstance(stride, torch.Tensor) else stride))
+    steady state does no device-to-host copy (a device-resident stride is read once, see _stride_values).  half_model: the
+    anchor_grid of a half-precision model (yolo.py:79-80) -- the fp16 anchors buffer times the stride, rounded to fp16,
+    then .float()."""
+    svals = _stride_values(stride)
     key = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), svals, bool(half_model))
     hit = _ANCHOR_CACHE.get(key)
     if hit is not None and hit[0]() is anchors:      # same address and version but another tensor: reused storage

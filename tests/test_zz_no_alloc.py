@@ -47,6 +47,10 @@ def test_noalloc_nms_matches_nms_on_two_calls_in_a_row():
     got_small = _noalloc(*small, 0.45)
     assert got_big.numel() == want_big.numel() > 1000 and torch.equal(got_big, want_big)
     assert got_small.numel() == want_small.numel() > 50 and torch.equal(got_small, want_small)
+    # and against the CPU oracle's greedy NMS (the published torchvision algorithm; no torchvision here to pin it further)
+    from oracle import nms as onms
+    for (b, s), thr, got in ((big, 0.5, got_big), (small, 0.45, got_small)):
+        assert torch.equal(got.cpu(), onms.nms(b.cpu(), s.cpu(), thr))
     # once more the other way round, and the largest size the array holds
     assert torch.equal(_noalloc(*small, 0.45), want_small)
     top = _boxes(rs, 32768)
