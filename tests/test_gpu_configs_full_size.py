@@ -111,6 +111,24 @@ def test_config5_sweep_share_16x100800_vs_oracle():
     two_step = non_max_suppression(dec, **kw)
     for g, w in zip(conv_nms(convs, 3, anchors, stride, **kw), two_step):
         assert torch.equal(g, w)
-    # and the device's rows against the oracle's: same counts unless a score sits within rounding of a threshold
-    close_counts = sum(int(a.shape[0] == b.shape[0]) for a, b in zip(two_step, want))
-    assert close_counts >= 14
+    # End to end, the device's own decode against the oracle's: the decoded values differ in their last bits (1e-5), so
+    # the rows can only be expected to be the same detections where every decision has margin.  An image has margin when the
+    # oracle's rows stay the same with both thresholds moved by 1e-4 either way (no score within 1e-4 of conf_thres, no
+    # compared IoU within 1e-4 of iou_thres) and no two neighbouring scores of its result lie within 1e-5 of each other
+    # (their order is what the greedy scan follows).  Those images must give the same rows in the same order, values within
+    # the decode tolerance; half of the images are of that kind (300 rows each: a pair of neighbouring scores within 1e-5 is common).
+    moved = [oracle_nms_per_image(want_dec, conf_thres=0.001 * c, iou_thres=0.6 + d, multi_label=True)
+             for c, d in ((1 - 1e-4, 0.0), (1 + 1e-4, 0.0), (1.0, -1e-4), (1.0, 1e-4))]
+    with_margin = 0
+    for i, (g, w) in enumerate(zip(two_step, want)):
+        conf = w[:, 4]
+        gaps = (conf[:-1] - conf[1:]).abs() > 1e-5 * conf[:-1]
+        if not (all(torch.equal(m[i], w) for m in moved) and bool(gaps.all())):
+            continue
+        with_margin += 1
+        g = g.cpu()
+        assert g.shape == w.shape, (i, g.shape, w.shape)
+        assert torch.equal(g[:, 5], w[:, 5]), f"image {i}: classes differ"
+        torch.testing.assert_close(g[:, :4], w[:, :4], rtol=1e-5, atol=1e-5 * 32 * 2)      # corners: xy -+ wh/2, coarsest stride
+        torch.testing.assert_close(g[:, 4], w[:, 4], rtol=2e-5, atol=1e-7)                   # obj * cls
+    assert with_margin >= 6, with_margin          # 8 of the 16 images with this seed
