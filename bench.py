@@ -94,11 +94,22 @@ def plant_objects(levels, targets, crit):
     return sum(int(i[0].numel()) for i in indices)
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """The CPU oracle (restatement of the reference's PyTorch path) on a bounded sample: bs 8 of the same workload."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_config(bs, nt, seconds_budget, val_nms=True):
+    """One configuration of the workload on the CPU oracle, stage by stage: {stage: seconds per call}, reps."""
     from oracle import nms as onms
     from oracle import yolo as oy
-    bs, img, nc, nt = 8, 640, 80, 80
+    img, nc = 640, 80
     torch.manual_seed(0)
     levels, targets = synth_batch(bs, img, nc, nt, 4242, "cpu")
     anchors = oy.grid_anchors()
@@ -110,27 +121,71 @@ def cpu_baseline(seconds_budget=12.0):
             levels[l][b, a, gj, gi, 4] = 1.5 + torch.randn(b.numel())
             levels[l][b, a, gj, gi, 5 + torch.from_numpy(t["tcls"])] = 2.0 + torch.randn(b.numel())
             levels[l][b, a, gj, gi, 0:4] *= 0.3
+    state = {}
 
-    def step():
-        z = oy.detect_decode([x.detach() for x in levels], anchors, [float(s) for s in STRIDES])
+    def decode():
+        state["z"] = oy.detect_decode([x.detach() for x in levels], anchors, [float(s) for s in STRIDES])
+
+    def assign():
+        crit.targets_for(levels, targets)
+
+    def loss_fwd_bwd():      # includes the assignment, as ComputeLoss.__call__ does (loss.py:120)
         p = [x.detach().requires_grad_(True) for x in levels]
         loss, _ = crit(p, targets)
         torch.autograd.grad(loss, p)
-        onms.non_max_suppression(z, 0.25, 0.45, max_det=300)
 
-    step()
-    t0 = time.perf_counter()
-    reps = 0
-    while reps < 3 or (time.perf_counter() - t0 < seconds_budget and reps < 2000):
-        step()
+    def nms_infer():
+        onms.non_max_suppression(state["z"], 0.25, 0.45, max_det=300)
+
+    def nms_val():            # ~20 000 candidates per image: seconds per image on a CPU, so two images stand for the batch
+        onms.non_max_suppression(state["z"][:2], 0.001, 0.6, multi_label=True, max_det=300)
+
+    stages = (("decode", decode), ("assign", assign), ("loss_fwd_bwd", loss_fwd_bwd), ("nms_conf0.25_iou0.45", nms_infer))
+    spent = {k: 0.0 for k, _ in stages}
+    for _ in range(2):        # warm-up: first calls pay for allocator and thread-pool start
+        for _, fn in stages:
+            fn()
+    t_start, reps = time.perf_counter(), 0
+    while reps < 2 or (time.perf_counter() - t_start < seconds_budget and reps < 500):
+        for k, fn in stages:
+            t0 = time.perf_counter()
+            fn()
+            spent[k] += time.perf_counter() - t0
         reps += 1
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": round(bs / dt, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"bs {bs} @ {img}px, {nt} targets, {reps} reps of decode+assign+loss fwd/bwd+NMS on the CPU oracle "
-                      f"(PyTorch-CPU restatement + C greedy NMS), {dt * 1e3:.1f} ms/step"}
+    per = {k: v / reps for k, v in spent.items()}
+    if val_nms:
+        t0 = time.perf_counter()
+        nms_val()
+        per["nms_conf0.001_iou0.6_multilabel_per_image"] = (time.perf_counter() - t0) / 2
+    return per, reps
 
 
-PMC_FILES = ("r2_pmc_traffic.json", "r1_pmc_traffic.json")      # newest first
+CPU_CONFIGS = {"cfg1_bs8": (8, 80, 0.25), "cfg2_bs64": (64, 640, 0.4)}      # batch, targets, share of the time budget
+
+
+def cpu_baseline(seconds_budget=12.0, configs=("cfg1_bs8", "cfg2_bs64"), val_nms=True):
+    """The CPU oracle (restatement of the reference's PyTorch path, pinned to it by the golden fixtures) on bounded samples
+    of the same workload, stage by stage: configuration 1 (bs 8, the reference's CPU-runnable case) and configuration 2
+    (bs 64, the one the metric is quoted on).  `value` is the last configuration's images/s over the stages of the benchmark step
+    (decode + loss forward/backward incl. assignment + NMS at conf 0.25 / IoU 0.45)."""
+    out = {}
+    for name in configs:
+        bs, nt, share = CPU_CONFIGS[name]
+        per, reps = _cpu_config(bs, nt, seconds_budget * share, val_nms)
+        step = per["decode"] + per["loss_fwd_bwd"] + per["nms_conf0.25_iou0.45"]
+        out[name] = {"images_per_s": round(bs / step, 2), "ms_per_step": round(step * 1e3, 2), "reps": reps,
+                     "stage_ms": {k: round(v * 1e3, 3) for k, v in per.items()}}
+    head, (hbs, hnt, _) = out[configs[-1]], CPU_CONFIGS[configs[-1]]
+    return {"value": head["images_per_s"], "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "os_cpu_count": os.cpu_count(), "torch_num_threads": torch.get_num_threads(), "cpu_model": _cpu_model(),
+            "sample": f"bs {hbs} @ 640px, {hnt} targets, {head['reps']} reps of decode + assign + loss fwd/bwd + NMS(0.25, 0.45) on the CPU "
+                      f"oracle (PyTorch-CPU restatement with torch's intra-op threads; C greedy NMS, one image after the other as "
+                      f"in the reference), {head['ms_per_step']:.1f} ms/step; stage_ms.assign is part of loss_fwd_bwd; the "
+                      f"validation-threshold NMS (conf 0.001, multi-label) is timed beside the step on two images, once",
+            "configs": out}
+
+
+PMC_FILES = ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")      # newest first
 
 
 def load_pmc_traffic():
@@ -529,6 +584,22 @@ def main():
         c1.record()
         torch.cuda.synchronize()
         roofline["device_copy_gbs"] = round(decode_bytes * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+        # the same bytes through the library's plain streaming copy (one 16-byte load and store per thread): the highest
+        # copy rate a kernel reaches on this memory system, i.e. the measured ceiling for the decode launch
+        from object_detection_amd import _lib as L
+        nbytes = src_c.numel() * 4 // 16 * 16
+        best = None
+        for _ in range(5):
+            c0.record()
+            for _ in range(10):
+                L.check(L.lib().dh_stream_copy(L.ptr(src_c), L.ptr(dst_c), nbytes, L.stream()), "dh_stream_copy")
+            c1.record()
+            torch.cuda.synchronize()
+            ms = c0.elapsed_time(c1) / 10
+            best = ms if best is None else min(best, ms)
+        roofline["stream_copy_gbs"] = round(2.0 * nbytes / (best * 1e-3) / 1e9, 1)
+        roofline["stream_copy_ms"] = round(best, 4)
+        roofline["frac_of_stream_copy"] = round(achieved / roofline["stream_copy_gbs"], 4)
         del src_c, dst_c
 
     if rank == 0:

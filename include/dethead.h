@@ -520,6 +520,11 @@ int dh_regression_loss_fwd(const float* pred, const float* target, const float* 
 int dh_regression_loss_bwd(const float* pred, const float* target, const float* mask, int64_t B, int64_t S, int smooth,
                            const float* out2, const float* grad_out, float* grad_pred, void* stream);
 
+/* Measurement aid, no counterpart in the reference: copies `bytes` (a multiple of 16, both pointers 16-byte aligned) with
+ * one 16-byte non-temporal load and store per thread.  bench.py times it on the bytes of one decode launch: the copy rate
+ * this memory system gives a kernel that only moves data, reported beside the nominal 8 TB/s. */
+int dh_stream_copy(const void* src, void* dst, size_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

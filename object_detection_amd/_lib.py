@@ -118,6 +118,7 @@ SIGNATURES = {
                                    c_size_t, c_void_p]),
     "dh_yolo_loss_bwd_scaled": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dh_stream_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dh_box_iou": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "dh_wh_iou": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_void_p]),
     "dh_centernet_pool_nms": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_int, c_int, c_void_p]),

@@ -75,9 +75,11 @@ def test_only_the_checkers_import_the_oracle():
 def test_bench_cpu_baseline_leg_runs_on_the_oracle():
     """bench.py's cpu_baseline leg is the oracle on a bounded sample; it must work without a GPU."""
     import bench
-    out = bench.cpu_baseline(seconds_budget=0.2)
+    out = bench.cpu_baseline(seconds_budget=0.2, configs=("cfg1_bs8",), val_nms=False)      # (the default also times bs 64)
     assert out["kind"] == "port" and out["unit"] == "images/s" and out["value"] > 0 and out["cores"] >= 1
-    assert "bs 8" in out["sample"]
+    assert "bs 8" in out["sample"] and out["os_cpu_count"] >= 1 and out["cpu_model"]
+    stages = out["configs"]["cfg1_bs8"]["stage_ms"]
+    assert set(stages) == {"decode", "assign", "loss_fwd_bwd", "nms_conf0.25_iou0.45"} and all(v > 0 for v in stages.values())
 
 
 def test_host_side_metric_helpers_match_the_oracle():
