@@ -247,6 +247,9 @@ def main():
     ap.add_argument("--early-positives", action="store_true",
                     help="target assignment and the positives' forward on a side stream beside the decode (they read only "
                          "the targets and the raw maps); measured slower than keeping them on the main stream")
+    ap.add_argument("--nms-first", action="store_true",
+                    help="enqueue the NMS chain (side stream) before the loss (main stream) instead of after it, so that its "
+                         "candidate search can start right behind the decode, beside the loss's short kernels")
     ap.add_argument("--autograd", action="store_true",
                     help="call loss = crit(p, t); autograd.grad(loss, p) instead of crit.forward_backward(p, t): same kernels, "
                          "plus the autograd engine's hop to its device thread and back (two thread wake-ups per step)")
@@ -340,7 +343,8 @@ def main():
         else:
             loss, items = crit(p, targets)
             grads = torch.autograd.grad(loss, p)
-        return loss, items, grads, crit.last_sums        # (nl, 5) float64 sums and divisors, written by the loss kernel
+        # (nl, 5) float64 sums and divisors, written by the loss kernel; the view is only built when it travels
+        return loss, items, grads, (crit.last_sums if dist_on else None)
 
     host_s = {s: 0.0 for s in stages + ("finish",)}
     # Three HIP streams: decode on the main stream; the NMS chain (short, latency-bound kernels that read the decoded
@@ -357,6 +361,9 @@ def main():
     nms_stream = torch.cuda.Stream(priority=int(os.environ.get("DH_BENCH_NMS_PRIORITY", "0"))) if overlap else main_stream
     loss_stream = torch.cuda.Stream() if n_streams == 3 else main_stream
     early = overlap and not args.autograd and args.early_positives
+    nms_first = overlap and args.nms_first
+    # diagnostic: how fast the main stream runs with no NMS chain beside it (the line is then marked invalid)
+    skip_nms, skipped, first_call = bool(os.environ.get("DH_BENCH_SKIP_NMS")), {}, [True]
     pos_stream = torch.cuda.Stream(priority=int(os.environ.get("DH_BENCH_POS_PRIORITY", "0"))) if early else None
     set_stream = torch.cuda.set_stream
     split = {"prev_stats": None, "reduced": None, "local_of_reduced": None}
@@ -397,23 +404,42 @@ def main():
             if n_streams == 3:
                 loss_stream.wait_event(decoded)
                 set_stream(loss_stream)
-        if detail: marks[6].record()
-        if early:
-            torch.cuda.current_stream().wait_event(pos_done)
-            loss, items, grads = crit.forward_backward(p, targets, positives=positives)
-            stats = crit.last_sums
+        def enqueue_loss():
+            if detail: marks[6].record()
+            if early:
+                torch.cuda.current_stream().wait_event(pos_done)
+                out = crit.forward_backward(p, targets, positives=positives) + ((crit.last_sums if dist_on else None),)
+            else:
+                out = f_loss()
+            if detail: marks[2].record()
+            return out
+
+        def enqueue_nms():
+            if overlap:
+                nms_stream.wait_event(decoded)
+                set_stream(nms_stream)
+            if detail: marks[3].record()
+            if skip_nms and not first_call[0]:      # diagnostic only (DH_BENCH_SKIP_NMS): reuse the first step's NMS results
+                rows, meta = skipped["rows"], skipped["meta"]
+            else:
+                rows, meta, _ = nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
+                skipped["rows"], skipped["meta"], first_call[0] = rows, meta, False
+            if detail: marks[4].record()
+            host_meta, copied = nms_meta_to_host(meta)           # the step's only device-to-host copy (4*bs ints)
+            if detail: marks[5].record()
+            return rows, host_meta, copied
+
+        if nms_first:      # the NMS chain is handed to the GPU before the loss: see --nms-first
+            rows, host_meta, copied = enqueue_nms()
+            set_stream(loss_stream if n_streams == 3 else main_stream)
+            h2 = time.perf_counter()
+            loss, items, grads, stats = enqueue_loss()
+            if overlap:
+                set_stream(nms_stream)      # the collective below rides on the side stream
         else:
-            loss, items, grads, stats = f_loss()
-        if detail: marks[2].record()
-        h2 = time.perf_counter()
-        if overlap:
-            nms_stream.wait_event(decoded)
-            set_stream(nms_stream)
-        if detail: marks[3].record()
-        rows, meta, _ = nms_launch(z, 0.25, 0.45, max_det=300, cap=cap)
-        if detail: marks[4].record()
-        host_meta, copied = nms_meta_to_host(meta)           # the step's only device-to-host copy (4*bs ints)
-        if detail: marks[5].record()
+            loss, items, grads, stats = enqueue_loss()
+            h2 = time.perf_counter()
+            rows, host_meta, copied = enqueue_nms()
         if dist_on:
             # The collective runs on the side stream, so the next decode never waits for the other ranks.  With two
             # streams it reduces the PREVIOUS step's loss statistics: the side stream has just waited for this step's
@@ -632,6 +658,8 @@ def main():
                         3: "decode | nms chain | assign+loss on three streams (stage_ms overlap)"}[n_streams],
             "roofline": roofline,
         }
+        if skip_nms:
+            line["INVALID"] = "DH_BENCH_SKIP_NMS: the NMS chain ran in the first step only"
         if base is not None:
             line["cpu_baseline"] = base
         print(json.dumps(line))

@@ -97,11 +97,24 @@ def _check_levels(maps, assign, nc, na, conv):
     return bs
 
 
+class _Sums:
+    """Where the loss kernels left their (nl, 5) float64 block of sums -- per level [sum(1 - iou), sum class BCE, sum
+    objectness BCE, assigned rows, cells]: the means of loss.py:136,149,155 before the division -- inside a workspace.
+    Kept as a recipe: the view is only built when somebody asks for it (a training step that does not report global loss
+    terms never does)."""
+    __slots__ = ("ws", "geometry")
+
+    def __init__(self, ws, assign, bs, na, nc, nl):
+        self.ws, self.geometry = ws, (assign.ny, assign.nx, nl, bs, na, nc, assign.cap)
+
+    def view(self):
+        ny, nx, nl, bs, na, nc, cap = self.geometry
+        off = L.lib().dh_yolo_loss_sums_offset(L.int_array(ny), L.int_array(nx), nl, bs, na, nc, cap)
+        return self.ws[off:off + 40 * nl].view(torch.float64).view(nl, 5)
+
+
 def _sums_view(ws, assign, bs, na, nc, nl):
-    """The (nl, 5) float64 block the loss kernels leave in their workspace: per level [sum(1 - iou), sum class BCE,
-    sum objectness BCE, assigned rows, cells] -- the means of loss.py:136,149,155 before the division."""
-    off = L.lib().dh_yolo_loss_sums_offset(L.int_array(assign.ny), L.int_array(assign.nx), nl, bs, na, nc, assign.cap)
-    return ws[off:off + 40 * nl].view(torch.float64).view(nl, 5)
+    return _Sums(ws, assign, bs, na, nc, nl)
 
 
 def _loss_fwd(assign, hyp, nc, maps, conv_na=0):
@@ -339,7 +352,7 @@ class ComputeLoss:
         self.sort_obj_iou = False
         self.last_positive_counts = None
         self.last_stats = None
-        self.last_sums = None
+        self._last_sums = None
         h = model.hyp
         self.cp, self.cn = smooth_BCE(eps=h.get('label_smoothing', 0.0))
         det = model.module.model[-1] if is_parallel(model) else model.model[-1]
@@ -348,6 +361,17 @@ class ComputeLoss:
         self.gr, self.hyp, self.autobalance = 1.0, h, autobalance
         for k in 'na', 'nc', 'nl', 'anchors':
             setattr(self, k, getattr(det, k))
+
+    @property
+    def last_sums(self):
+        """(nl, 5) float64 on the device, written by the last call's kernels: per level [sum(1 - iou), sum class BCE, sum
+        objectness BCE, assigned rows, cells].  A view of that call's workspace."""
+        src = self._last_sums
+        return src.view() if isinstance(src, _Sums) else src
+
+    @last_sums.setter
+    def last_sums(self, value):
+        self._last_sums = value
 
     def _hyp_struct(self):
         h = self.hyp
@@ -472,7 +496,7 @@ class ComputeLoss:
         hyp, nc, nl, bs = self._hyp_struct(), int(self.nc), len(maps), int(maps[0].shape[0])
         assign = _assign(shapes, targets, self.anchors, self.hyp['anchor_t'])
         out, ws = _loss_fwd(assign, hyp, nc, maps, conv_na=na if convs is not None else 0)
-        local = _sums_view(ws, assign, bs, na, nc, nl)
+        local = _sums_view(ws, assign, bs, na, nc, nl).view()
         total, world = local.clone(), 1
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)

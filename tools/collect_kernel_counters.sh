@@ -4,7 +4,7 @@
 #              python tools/pmc_by_grid.py profiles/<tag>_pmc_kernels.json gpurun_out/<tag>/fetch gpurun_out/<tag>/write gpurun_out/<tag>/sqa gpurun_out/<tag>/sqb
 set -e
 R=$GRAFT_REPO_ROOT
-S=${1:-pairwise,cnloss,cndecode,head16,convval,iou}
+S=${1:-pairwise,iou,cnloss,cndecode,convval,head}
 O=$R/gpurun_out/${2:-r3k}
 mkdir -p $O/kt $O/fetch $O/write $O/sqa $O/sqb
 cd /tmp; export TMPDIR=/tmp

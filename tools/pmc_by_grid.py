@@ -73,12 +73,18 @@ def main():
     for src in args:
         for f in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
             seen = set()
-            for r in csv.DictReader(open(f)):
+            phase = 0
+            for r in sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"])):
                 k = name_of(r["Kernel_Name"])
-                if not k or (only and not any(s in k for s in only)):
+                if not k:
                     continue
                 wg = max(int(r["Workgroup_Size"]), 1)
-                key = (k, int(r["Grid_Size"]) // wg)
+                if k == "k_stream_copy":      # a marker of tools/pmc_kernels.py: the launches that follow belong to this group
+                    phase = int(r["Grid_Size"]) // wg
+                    continue
+                if only and not any(s in k for s in only):
+                    continue
+                key = (phase, k, int(r["Grid_Size"]) // wg)
                 vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta[key] = dict(threads_per_wg=wg, vgprs=int(r["VGPR_Count"]), sgprs=int(r["SGPR_Count"]), lds_bytes=int(r["LDS_Block_Size"]),
                                  scratch=int(r["Scratch_Size"]))
@@ -87,16 +93,23 @@ def main():
                     dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     out = {"note": "medians over the launches of the passes; durations under counter collection (serialised dispatches) are a few "
                    "percent longer than in a plain kernel trace: use the kernel-trace file for timings", "kernels": {}}
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from pmc_kernels import PHASES
+    except Exception:
+        PHASES = {}
     for key in sorted(vals):
-        k, grid = key
+        ph, k, grid = key
         e = dict(meta[key])
+        if ph:
+            e["group"] = f"{ph}: {PHASES.get(ph, '')}"
         e["workgroups"] = grid
         e["waves_per_simd_by_vgprs"] = min(8, 512 // max((e["vgprs"] + 7) // 8 * 8, 8))
         e["launches"] = max(len(v) for v in vals[key].values())
         e["avg_us"] = round(st.mean(dur[key]), 2)
         e["counters"] = {c: st.median(v) for c, v in sorted(vals[key].items())}
         e["derived"] = derive(e)
-        out["kernels"][f"{k} @ {grid} wg"] = e
+        out["kernels"][f"{k} @ {grid} wg" + (f" [group {ph}]" if ph else "")] = e
     json.dump(out, open(out_path, "w"), indent=1)
     for name, e in out["kernels"].items():
         print(name, e["avg_us"], "us", e["derived"])
