@@ -107,9 +107,16 @@ class _Sums:
     def __init__(self, ws, assign, bs, na, nc, nl):
         self.ws, self.geometry = ws, (assign.ny, assign.nx, nl, bs, na, nc, assign.cap)
 
+    _offsets = {}
+
     def view(self):
         ny, nx, nl, bs, na, nc, cap = self.geometry
-        off = L.lib().dh_yolo_loss_sums_offset(L.int_array(ny), L.int_array(nx), nl, bs, na, nc, cap)
+        key = (tuple(ny), tuple(nx), nl, bs, na, nc, cap)
+        off = _Sums._offsets.get(key)
+        if off is None:
+            if len(_Sums._offsets) > 64:
+                _Sums._offsets.clear()
+            off = _Sums._offsets[key] = L.lib().dh_yolo_loss_sums_offset(L.int_array(ny), L.int_array(nx), nl, bs, na, nc, cap)
         return self.ws[off:off + 40 * nl].view(torch.float64).view(nl, 5)
 
 
