@@ -32,10 +32,12 @@ static inline int dh_cu_count()
 }
 
 // Every fill of the library goes through this kernel, not through hipMemsetAsync.  A memset captured into a HIP graph is a
-// memset node, and on this runtime (ROCm 7.2) memset nodes are not reliable once several are replayed in turn: a captured
-// 12-byte fill with 0 that follows a 4-byte one wrote 0x0C bytes on every second replay (tools/graph_memset_probe.py).  The
-// NMS and loss bookkeeping start from an all-zero (or all-ones) state, so a wrong fill value there turns counters into wild
-// indices.  A kernel node replays like any other launch.
+// memset node; a fill kernel is a kernel node and replays like any other launch.  The NMS and loss bookkeeping start from an
+// all-zero (or all-ones) state and derive indices from it, so the library does not depend on how a runtime replays memset
+// nodes.  (A three-graph replay of a full-size step faulted while the fills were memsets and has replayed correctly since
+// they are kernels and the consumers of the counters clamp what they read; stand-alone probes of captured memsets --
+// tools/micro/graph_memset.hip, tools/graph_memset_probe.py -- replay correctly on ROCm 7.2, so the memset nodes are not
+// shown to have been the cause.)
 template <typename V>
 __global__ void __launch_bounds__(256) dh_k_fill(V* __restrict__ p, V value, size_t n)
 {

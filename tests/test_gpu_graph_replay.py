@@ -1,7 +1,7 @@
 """HIP-graph capture and replay of the three stages of a step (decode, assignment + loss forward/backward, NMS), each its own
 graph with its own memory pool, replayed in turn and mixed with eager calls: every replay reproduces the eager results.
-Every fill the library needs is a kernel node (a captured hipMemsetAsync is a memset node, and those replay with wrong
-fill values on this runtime), so the bookkeeping of NMS and loss starts from the right state on every replay."""
+Every fill the library needs is a kernel node (not a captured hipMemsetAsync), and the consumers of the counters clamp what
+they read, so the bookkeeping of NMS and loss starts from the right state on every replay."""
 import pytest
 
 pytestmark = pytest.mark.gpu
