@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r2p
+O=$R/gpurun_out/${1:-r3p}
 mkdir -p $O/tc $O/pf_fetch $O/pf_write $O/kt $O/fetch $O/write
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tc -- python3 $R/tools/time_configs.py val,dense,sweep > $O/tc.log 2>&1
