@@ -21,7 +21,7 @@ import sys
 
 
 def name_of(raw):
-    m = re.search(r"((?:dh_)?k_[a-z0-9_]+)(<[^>]*>)?", raw)
+    m = re.search(r"(?<![A-Za-z0-9_])((?:dh_)?k_[a-z0-9_]+)(<[^>]*>)?", raw)
     if m:
         return m.group(0)
     m = re.search(r"\d+(k_[a-z0-9_]+)I(.*?)EEv", raw)
