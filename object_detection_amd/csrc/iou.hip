@@ -359,7 +359,7 @@ extern "C" int dh_centernet_box_loss_bwd(const float* pred_xy, int64_t pred_xy_b
 {
     const cn_maps mp = {pred_xy, pred_xy_bstride, pred_wh, pred_wh_bstride, tgt_xy, tgt_xy_bstride, tgt_wh, tgt_wh_bstride, mask};
     if (!cn_args_ok(mp, B, W, H) || !fwd_out2 || !grad_out || !grad_xy || !grad_wh) return DH_ERR_ARG;
-    if (grad_xy_bstride % 4 || grad_wh_bstride % 4) return DH_ERR_ARG;
+    if (grad_xy_bstride % 4 || grad_wh_bstride % 4 || grad_xy_bstride < 2ll * W * H || grad_wh_bstride < 2ll * W * H) return DH_ERR_ARG;
     if (!cn_aligned(mp) || !dh_aligned16(grad_xy) || !dh_aligned16(grad_wh)) return DH_ERR_ALIGN;
     const cn_grads gr = {grad_xy, grad_xy_bstride, grad_wh, grad_wh_bstride};
     hipLaunchKernelGGL(k_cn_loss_bwd<false>, dim3(cn_grid_x(B, W, H), B), dim3(256), 0, (hipStream_t)stream, mp, gr, W,
@@ -379,7 +379,7 @@ extern "C" int dh_centernet_box_loss_fwd_bwd(const float* pred_xy, int64_t pred_
 {
     const cn_maps mp = {pred_xy, pred_xy_bstride, pred_wh, pred_wh_bstride, tgt_xy, tgt_xy_bstride, tgt_wh, tgt_wh_bstride, mask};
     if (!cn_args_ok(mp, B, W, H) || !out2 || !workspace || !grad_xy || !grad_wh) return DH_ERR_ARG;
-    if (grad_xy_bstride % 4 || grad_wh_bstride % 4) return DH_ERR_ARG;
+    if (grad_xy_bstride % 4 || grad_wh_bstride % 4 || grad_xy_bstride < 2ll * W * H || grad_wh_bstride < 2ll * W * H) return DH_ERR_ARG;
     if (!cn_aligned(mp) || !dh_aligned16(grad_xy) || !dh_aligned16(grad_wh) || (reinterpret_cast<uintptr_t>(workspace) & 7u))
         return DH_ERR_ALIGN;
     if (workspace_bytes < dh_centernet_box_loss_workspace(B, W, H)) return DH_ERR_WORKSPACE;

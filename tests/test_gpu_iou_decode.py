@@ -147,6 +147,33 @@ def test_centernet_box_loss_forward_backward_bs64_vs_oracle():
     close(gs, wsz)
 
 
+def test_centernet_box_loss_entries_reject_bad_layouts():
+    """Through the C ABI: gradient planes that would overlap (batch stride below 2*W*H), misaligned pointers, a short
+    workspace and a cell count that is not a multiple of four are refused before anything is launched."""
+    from object_detection_amd import _lib as L
+    lib = L.lib()
+    B, W, H = 2, 8, 8
+    xy, wh, txy, twh = (torch.rand(B, 2, W, H, device="cuda") for _ in range(4))
+    mask = torch.ones(B, W, H, device="cuda")
+    gxy, gwh = torch.full_like(xy, 7.0), torch.full_like(wh, 7.0)
+    out2 = torch.zeros(2, device="cuda")
+    ws_bytes = lib.dh_centernet_box_loss_workspace(B, W, H)
+    ws = torch.empty(ws_bytes + 16, dtype=torch.uint8, device="cuda")
+    bst = 2 * W * H
+
+    def call(gx=gxy, gxs=bst, gws=bst, wsb=ws_bytes, pxy=xy, w=W):
+        return lib.dh_centernet_box_loss_fwd_bwd(L.ptr(pxy), bst, L.ptr(wh), bst, L.ptr(txy), bst, L.ptr(twh), bst, L.ptr(mask), B, w, H, 1,
+                                                 1e-7, None, L.ptr(out2), L.ptr(gx), gxs, L.ptr(gwh), gws, L.ptr(ws), wsb, L.stream())
+    assert call() == 0
+    torch.cuda.synchronize()
+    assert not (gxy == 7.0).any() and not (gwh == 7.0).any()
+    assert call(gxs=W * H) == -1 and call(gws=bst - 4) == -1                    # DH_ERR_ARG: overlapping gradient planes
+    assert call(wsb=ws_bytes - 8) == -4                                          # DH_ERR_WORKSPACE
+    assert call(gx=gxy.flatten()[1:]) == -3 and call(pxy=xy.flatten()[1:]) == -3   # DH_ERR_ALIGN
+    assert lib.dh_centernet_box_loss_fwd_bwd(L.ptr(xy), 2 * 3 * 3, L.ptr(wh), 18, L.ptr(txy), 18, L.ptr(twh), 18, L.ptr(mask), B, 3, 3, 1,
+                                             1e-7, None, L.ptr(out2), L.ptr(gxy), 18, L.ptr(gwh), 18, L.ptr(ws), ws_bytes, L.stream()) == -1
+
+
 @pytest.mark.parametrize("tag", ["pos", "zero", "dense"])
 def test_centernet_box_loss(golden, tag):
     from object_detection_amd.centernet import compute_losses
