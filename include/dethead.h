@@ -45,7 +45,9 @@ int dh_bbox_iou_bwd(const float* box1, int64_t s1_comp, int64_t s1_elem, const f
  * Serves IoULossWithMask.forward (object_detection/loss.py:109-115) and, with add_coords != 0,
  * the box branch of compute_losses incl. offset_to_coord
  * (object_detection/detectors/centernet/loss.py:4-13,22-28).
- * out2[0] = 1 - sum(CIoU)/(4*sum(mask)+1e-4), out2[1] = that divisor (kept for the backward). */
+ * out2[0] = 1 - sum(CIoU)/(4*sum(mask)+1e-4), out2[1] = that divisor (kept for the backward).
+ * Layout: W*H a multiple of 4, 16-byte aligned pointers; a *_bstride is the distance in floats between two images of
+ * that tensor (a multiple of 4, at least 2*W*H), so the planes may be slices of a wider head output. */
 size_t dh_centernet_box_loss_workspace(int B, int W, int H);
 int dh_centernet_box_loss_fwd(const float* pred_xy, int64_t pred_xy_bstride, const float* pred_wh,
                               int64_t pred_wh_bstride, const float* tgt_xy, int64_t tgt_xy_bstride,
