@@ -120,6 +120,102 @@ __global__ void __launch_bounds__(256) k_slot_fwd(const slot_params P, const flo
     }
 }
 
+// Path C: a wave takes 16 slots; every lane tests slot (lane & 15), and the rows that exist are worked on four at a time,
+// one per group of 16 lanes.  A lane of a group stands for four of the 64 lanes of the row-per-wave kernel (lane l for l, l+16,
+// l+32, l+48): it forms their class sums and the first two butterfly steps of the wave reduction by itself, and the last four
+// steps run across the group -- the same additions in the same tree, so the class sum has the same bits.
+// INTERLEAVE: the 16 slots of a wave lie n_waves apart (every wave sees every offset and anchor) instead of side by side.
+template <bool INTERLEAVE, int G>
+__global__ void __launch_bounds__(256) k_slot_fwd16(const slot_params P, const float* __restrict__ targets,
+                                                    const float* __restrict__ anchors, int* __restrict__ owner,
+                                                    int* __restrict__ nxt, float* __restrict__ iou_ws, float* __restrict__ cls_ws)
+{
+    const int l = blockIdx.y;
+    constexpr int U = 64 / G;          // lanes of the row-per-wave kernel one lane stands for = rows a wave works on at a time
+    const int lane = threadIdx.x & 63, slot_lane = lane & 15, sub = lane & (G - 1), grp = lane / G;
+    const long n_waves = (P.cap + 15) / 16;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_waves) return;
+    const long s = INTERLEAVE ? w + (long)slot_lane * n_waves : w * 16 + slot_lane;
+    const int nx = P.nx[l], ny = P.ny[l];
+    const float fnx = (float)nx, fny = (float)ny;
+    bool take = s < P.cap;
+    long cell = 0;
+    float tb0 = 0.f, tb1 = 0.f, tb2 = 0.f, tb3 = 0.f, an0 = 1.f, an1 = 1.f;
+    int cls = 0;
+    if (take) {
+        const int per_off = P.na * P.nt;
+        const int off = (int)(s / per_off), q = (int)(s - (long)off * per_off);
+        const int a = q / P.nt, t = q - a * P.nt;
+        const float* __restrict__ tr = targets + (size_t)t * 6;
+        an0 = anchors[((size_t)l * P.na + a) * 2]; an1 = anchors[((size_t)l * P.na + a) * 2 + 1];
+        const float gw = tr[4] * fnx, gh = tr[5] * fny;
+        const float rw = __fdiv_rn(gw, an0), rh = __fdiv_rn(gh, an1);
+        const float worst = fmaxf(fmaxf(rw, __fdiv_rn(1.0f, rw)), fmaxf(rh, __fdiv_rn(1.0f, rh)));
+        const float gx = tr[2] * fnx, gy = tr[3] * fny;
+        take = worst < P.anchor_t;
+        if (off == 1) take = take && (remainder_one(gx) < 0.5f) && (gx > 1.0f);
+        if (off == 2) take = take && (remainder_one(gy) < 0.5f) && (gy > 1.0f);
+        if (off == 3) { const float ix = fnx - gx; take = take && (remainder_one(ix) < 0.5f) && (ix > 1.0f); }
+        if (off == 4) { const float iy = fny - gy; take = take && (remainder_one(iy) < 0.5f) && (iy > 1.0f); }
+        const float ox = off == 1 ? 0.5f : (off == 3 ? -0.5f : 0.0f);
+        const float oy = off == 2 ? 0.5f : (off == 4 ? -0.5f : 0.0f);
+        long long gi = (long long)(gx - ox), gj = (long long)(gy - oy);
+        gi = gi < 0 ? 0 : (gi > nx - 1 ? nx - 1 : gi);
+        gj = gj < 0 ? 0 : (gj > ny - 1 ? ny - 1 : gj);
+        const long long b = (long long)tr[0];
+        take = take && b >= 0 && b < P.bs;
+        tb0 = gx - (float)gi; tb1 = gy - (float)gj; tb2 = gw; tb3 = gh;
+        cell = ((b * P.na + a) * ny + gj) * nx + gi;
+        cls = (int)tr[1];
+    }
+    float* __restrict__ iou_out = iou_ws + (size_t)l * P.cap;
+    float* __restrict__ cls_out = cls_ws + (size_t)l * P.cap;
+    int* __restrict__ nxt_l = nxt + (size_t)l * P.cap;
+    if (!take && lane < 16 && s < P.cap) { iou_out[s] = 1.0f; cls_out[s] = 0.0f; nxt_l[s] = -2; }
+    const unsigned mask = (unsigned)(__ballot(take) & 0xFFFFull);
+    const int count = __popc(mask);
+    for (int pass = 0; pass * U < count; ++pass) {
+        const int k = pass * U + grp;
+        const bool active = k < count;
+        unsigned m = mask;
+        for (int j = 0; j < k && j < 15; ++j) m &= m - 1;
+        const int src = active ? __ffs(m) - 1 : 0;
+        const long r_cell = __shfl(cell, src, 64);
+        const long r_s = __shfl(s, src, 64);
+        const float r_tb[4] = {__shfl(tb0, src, 64), __shfl(tb1, src, 64), __shfl(tb2, src, 64), __shfl(tb3, src, 64)};
+        const float r_an[2] = {__shfl(an0, src, 64), __shfl(an1, src, 64)};
+        const int r_cls = __shfl(cls, src, 64);
+        float iou = 0.0f, s16 = 0.0f;
+        if (active) {
+            const float* __restrict__ ps = P.p[l] + (size_t)r_cell * P.no;
+            const float x0 = ps[0], x1 = ps[1], x2 = ps[2], x3 = ps[3];
+            float V[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                V[u] = 0.0f;
+                for (int c = sub + G * u; c < P.nc; c += 64) V[u] += bce_plain(ps[5 + c], c == r_cls ? P.cp : P.cn, P.cls_pw);
+            }
+            const float px = dh_sigmoid(x0) * 2.0f - 0.5f, py = dh_sigmoid(x1) * 2.0f - 0.5f;
+            const float tw = dh_sigmoid(x2) * 2.0f, th = dh_sigmoid(x3) * 2.0f;
+            const float pw = (tw * tw) * r_an[0], ph = (th * th) * r_an[1];
+            iou = dh_iou_value<DH_CIOU>(dh_from_xywh(px, py, pw, ph), dh_from_xywh(r_tb[0], r_tb[1], r_tb[2], r_tb[3]), 1e-7f, (float)(1.0 + 1e-7));
+#pragma unroll
+            for (int du = U / 2; du > 0; du >>= 1)       // the butterfly steps 32 ... G of the 64-lane reduction, inside the lane
+#pragma unroll
+                for (int u = 0; u < du; ++u) V[u] = V[u] + V[u + du];
+            s16 = V[0];
+        }
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) s16 += __shfl_xor(s16, o, 64);
+        if (active && sub == 0) {
+            iou_out[r_s] = iou;
+            cls_out[r_s] = s16;
+            nxt_l[r_s] = atomicExch(owner + P.cell_first[l] + r_cell, (int)r_s);
+        }
+    }
+}
+
 // the same row arithmetic on the rows the library's assignment produced (the check of path B)
 __global__ void __launch_bounds__(256) k_rows_check(const slot_params P, const long long* __restrict__ idx,
                                                     const float* __restrict__ tbox, const float* __restrict__ anch,
@@ -221,9 +317,23 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL(k_slot_fwd, dim3((unsigned)((cap + 3) / 4), NL), dim3(256), 0, st, P, d_t, d_a, owner, nxt, iou_b, cls_b, counts_b);
     };
 
+    const long n_waves16 = (cap + 15) / 16;
+    int lanes_per_row = 16;
+    auto path_c = [&](bool interleave) {
+        hipLaunchKernelGGL(k_fill_map, dim3((unsigned)((vecs + 511) / 512)), dim3(256), 0, st, (uint4*)owner, vecs, counts_b);
+        const dim3 grid((unsigned)((n_waves16 + 3) / 4), NL);
+#define SLOT16(IL, G) hipLaunchKernelGGL((k_slot_fwd16<IL, G>), grid, dim3(256), 0, st, P, d_t, d_a, owner, nxt, iou_b, cls_b)
+        if (lanes_per_row == 16) { if (interleave) SLOT16(true, 16); else SLOT16(false, 16); }
+        else if (lanes_per_row == 8) { if (interleave) SLOT16(true, 8); else SLOT16(false, 8); }
+        else { if (interleave) SLOT16(true, 4); else SLOT16(false, 4); }
+#undef SLOT16
+    };
     // ---- check: B's valid slots, in slot order, are A's rows
+    long bad_total = 0;
+    for (int variant = 0; variant < 7; ++variant) {
     path_a();
-    path_b();
+    lanes_per_row = variant < 3 ? 16 : (variant < 5 ? 8 : 4);
+    if (variant == 0) path_b(); else path_c(variant % 2 == 0);
     hipLaunchKernelGGL(k_rows_check, dim3((unsigned)((cap + 3) / 4), NL), dim3(256), 0, st, P, idx, tbox, anch, tcls, counts_a, iou_c, cls_c);
     CHECK(hipStreamSynchronize(st));
     int ca[NL], cb[NL];
@@ -245,9 +355,12 @@ int main(int argc, char** argv)
                              // words took this kernel from 11 to 108 us)
         if (r != ca[l]) ++bad;
         total += ca[l];
-        printf("level %d: rows %d (library) %d (slots) of %ld slots\n", l, ca[l], cb[l], cap);
+        if (variant == 0) printf("level %d: rows %d (library) %d (slots) of %ld slots\n", l, ca[l], cb[l], cap);
     }
-    printf("rows %ld, mismatches %ld\n", total, bad);
+    if (variant == 0) printf("B (wave per slot): rows %ld, mismatches %ld\n", total, bad);
+    else printf("C (16 slots per wave, %d lanes per row, %s): rows %ld, mismatches %ld\n", lanes_per_row, variant % 2 == 0 ? "interleaved" : "side by side", total, bad);
+    bad_total += bad;
+    }
 
     // ---- timing, back to back on one stream
     hipEvent_t e0, e1;
@@ -264,6 +377,14 @@ int main(int argc, char** argv)
         for (int i = 0; i < reps; ++i) path_b();
         CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
         printf("B  fill -> one wave per slot                          %7.2f us per pair of launches\n", ms * 1000.0f / reps);
+        for (int il = 0; il < 6; ++il) {
+            lanes_per_row = il < 2 ? 16 : (il < 4 ? 8 : 4);
+            for (int i = 0; i < 20; ++i) path_c(il % 2 != 0);
+            CHECK(hipEventRecord(e0, st));
+            for (int i = 0; i < reps; ++i) path_c(il % 2 != 0);
+            CHECK(hipEventRecord(e1, st)); CHECK(hipEventSynchronize(e1)); CHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("C  fill -> 16 slots per wave, %2d lanes per row (%s) %7.2f us per pair of launches\n", lanes_per_row, il % 2 ? "interleaved" : "side by side", ms * 1000.0f / reps);
+        }
     }
-    return bad != 0;
+    return bad_total != 0;
 }
