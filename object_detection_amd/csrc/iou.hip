@@ -98,19 +98,25 @@ struct cn_cell {
     float m;
 };
 
+__device__ __forceinline__ float4 cn_ld4(const float* p)
+{
+    const dh_f4 v = __builtin_nontemporal_load(reinterpret_cast<const dh_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ void cn_load4(const cn_maps& mp, int b, long cell, long plane, dh_fastdiv H, int add_coords,
                                          float px[4], float py[4], float pw[4], float ph[4], float tx[4], float ty[4],
                                          float tw[4], float th[4], float m[4])
 {
-    const float4 a0 = *reinterpret_cast<const float4*>(mp.pxy + b * mp.pxy_b + cell);
-    const float4 a1 = *reinterpret_cast<const float4*>(mp.pxy + b * mp.pxy_b + plane + cell);
-    const float4 a2 = *reinterpret_cast<const float4*>(mp.pwh + b * mp.pwh_b + cell);
-    const float4 a3 = *reinterpret_cast<const float4*>(mp.pwh + b * mp.pwh_b + plane + cell);
-    const float4 c0 = *reinterpret_cast<const float4*>(mp.txy + b * mp.txy_b + cell);
-    const float4 c1 = *reinterpret_cast<const float4*>(mp.txy + b * mp.txy_b + plane + cell);
-    const float4 c2 = *reinterpret_cast<const float4*>(mp.twh + b * mp.twh_b + cell);
-    const float4 c3 = *reinterpret_cast<const float4*>(mp.twh + b * mp.twh_b + plane + cell);
-    const float4 mm = *reinterpret_cast<const float4*>(mp.mask + b * plane + cell);
+    const float4 a0 = cn_ld4(mp.pxy + b * mp.pxy_b + cell);
+    const float4 a1 = cn_ld4(mp.pxy + b * mp.pxy_b + plane + cell);
+    const float4 a2 = cn_ld4(mp.pwh + b * mp.pwh_b + cell);
+    const float4 a3 = cn_ld4(mp.pwh + b * mp.pwh_b + plane + cell);
+    const float4 c0 = cn_ld4(mp.txy + b * mp.txy_b + cell);
+    const float4 c1 = cn_ld4(mp.txy + b * mp.txy_b + plane + cell);
+    const float4 c2 = cn_ld4(mp.twh + b * mp.twh_b + cell);
+    const float4 c3 = cn_ld4(mp.twh + b * mp.twh_b + plane + cell);
+    const float4 mm = cn_ld4(mp.mask + b * plane + cell);
     px[0] = a0.x; px[1] = a0.y; px[2] = a0.z; px[3] = a0.w;
     py[0] = a1.x; py[1] = a1.y; py[2] = a1.z; py[3] = a1.w;
     pw[0] = a2.x; pw[1] = a2.y; pw[2] = a2.z; pw[3] = a2.w;
