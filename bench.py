@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0,
+                    help="time budget of the CPU baseline's repeated stages (the validation-threshold NMS sample comes on top)")
     ap.add_argument("--streams", type=int, default=2, choices=(1, 2, 3),
                     help="1: everything on one stream; 2: the NMS chain on a second stream; 3: NMS chain and loss on their own streams")
     ap.add_argument("--early-positives", action="store_true",
@@ -287,7 +289,7 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} of {world} needs device {local_rank}, this machine shows "
                          f"{torch.cuda.device_count()} (--gpus {world} needs {world} devices)")
     # the CPU baseline runs first (rank 0 of a single-GPU run), so that the GPU work is the last thing the process does
-    base = cpu_baseline() if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
+    base = cpu_baseline(seconds_budget=args.cpu_baseline_seconds) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
     backend = os.environ.get("DH_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
